@@ -1,0 +1,59 @@
+"""Pin the CPU oracle against outputs of the reference's own modules (tests/golden/*.npz,
+produced by tests/golden/make_golden.py from /root/reference/two_tower_model.py and
+transformer_ranker.py).  CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+from amdrec import synth
+from tests import cases
+from tests.conftest import load_golden
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_two_tower_oracle_matches_reference(name):
+    user, ad, nnum, sd, batches = cases.two_tower_case(name)
+    g = load_golden(f"two_tower_{name}.npz")
+    assert str(g["weights_sha256"]) == synth.state_sha256(sd), "seeded weight generator drifted"
+    for B in batches:
+        ucat, unum, acat = g[f"B{B}_user_cat"], g[f"B{B}_user_num"], g[f"B{B}_ad_cat"]
+        ue = oracle.towers.user_tower(sd, ucat, unum)
+        ae = oracle.towers.ad_tower(sd, acat)
+        assert np.abs(ue - g[f"B{B}_user_emb"]).max() <= cases.EMB_ATOL
+        assert np.abs(ae - g[f"B{B}_ad_emb"]).max() <= cases.EMB_ATOL
+        ps = oracle.towers.predict_scores(sd, ucat, unum, acat)
+        assert np.abs(ps - g[f"B{B}_scores"]).max() <= cases.EMB_ATOL
+        assert np.allclose(np.linalg.norm(ue, axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("cross", list(cases.CROSS))
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_ranker_oracle_matches_reference(name, cross):
+    user, ad, nnum, sd, batches = cases.ranker_case(name, cross)
+    g = load_golden(f"ranker_{name}_{cross}.npz")
+    assert str(g["weights_sha256"]) == synth.state_sha256(sd)
+    for B in batches:
+        pred = oracle.ranker.forward(sd, g[f"B{B}_user_cat"], g[f"B{B}_ad_cat"], g[f"B{B}_user_num"])
+        assert list(pred) == ["ctr", "engagement", "revenue"]
+        for t in pred:
+            ok, err = cases.logit_close(pred[t], g[f"B{B}_{t}"])
+            assert ok, (name, cross, B, t, err)
+
+
+def test_seq1_attention_is_degenerate():
+    """transformer_ranker.py:358 feeds seq_len 1: full 8-head attention == W_o(W_v x)."""
+    user, ad, nnum, sd, _ = cases.ranker_case("demo", "scaled")
+    ucat, unum = synth.user_batch(user, nnum, 9, seed=5)
+    acat = synth.ad_features(ad, 9, seed=6)
+    a = oracle.ranker.forward(sd, ucat, acat, unum, full_attention=False)
+    b = oracle.ranker.forward(sd, ucat, acat, unum, full_attention=True)
+    for t in a:
+        assert np.array_equal(a[t], b[t])
+
+
+def test_embedding_index_out_of_range_raises():
+    user, ad, nnum, sd, _ = cases.two_tower_case("demo")
+    ucat, unum = synth.user_batch(user, nnum, 2, seed=1)
+    ucat[1, 3] = 100
+    with pytest.raises(IndexError):
+        oracle.towers.user_tower(sd, ucat, unum)
