@@ -1,0 +1,105 @@
+"""ctypes binding of libamdrec.so (include/amdrec.h).
+
+There is no CPU fallback: if the library is missing or a call fails this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libamdrec.so")
+
+ABI_VERSION = 1
+MAX_K = 2048
+
+
+class AmdrecError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_i64, _i32, _sz, _vp, _fp = C.c_int64, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/amdrec.h
+_SIGNATURES = {
+    "amdrec_abi_version": [],
+    "amdrec_last_error": [],
+    "amdrec_flat_search_workspace": [_i64, _i64, _i32, C.POINTER(_sz)],
+    "amdrec_flat_search": [_fp, _i64, _i64, _i32, _fp, _i64, _i64, _i32, _i64, _fp, _vp, _vp, _sz, _vp, _vp],
+    "amdrec_l2_normalize": [_fp, _i64, _fp, _i64, _i64, _i32, _vp],
+    "amdrec_remap_ids": [_vp, _vp, _i64, _vp, _i64, _vp],
+}
+_RESTYPE = {"amdrec_last_error": C.c_char_p}
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def load():
+    """Load libamdrec.so once; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmdrecError(
+            f"{LIB_PATH} not found: build it with `python movie-recommender-demo_amd/build.py` "
+            "(there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    v = lib.amdrec_abi_version()
+    if v != ABI_VERSION:
+        raise AmdrecError(f"libamdrec ABI {v} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().amdrec_last_error()
+        raise AmdrecError(f"libamdrec error {status}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise AmdrecError(f"{name} must be a tensor on a HIP device (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise AmdrecError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+class Workspace:
+    """Grow-only per-device scratch buffer handed to the C ABI (caller-owned workspace)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes, device):
+        key = torch.device(device)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = None
+            self._buf[key] = None
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=key)
+            assert buf.data_ptr() % 256 == 0
+            self._buf[key] = buf
+        return buf
+
+
+WORKSPACE = Workspace()

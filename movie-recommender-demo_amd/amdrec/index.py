@@ -1,0 +1,318 @@
+"""Device-resident retrieval index: drop-in for the reference's ``FAISSIndex`` wrapper
+(faiss_retrieval.py:14-256) with the faiss calls replaced by libamdrec HIP kernels.
+
+Same constructor arguments, method names, argument meaning and return conventions:
+``search`` returns ``(ad_ids, distances)`` in that order (faiss_retrieval.py:164-166),
+numpy in / numpy out, inputs are never mutated (the wrapper copies via ``astype``,
+:114, :146), default ids are a running ``arange`` (:121-123), unknown ``index_type`` raises
+``ValueError`` (:73).  Extra, for the on-device pipeline: ``search_device`` takes and returns
+device tensors and never synchronises with the host.
+
+Layout in HBM: corpus ``[capacity, dimension]`` float32 row-major, rows L2-normalised at
+``add`` time, 1 KiB per row at d=256 (1.024 GB per 1M ads: the whole 10M corpus of
+BASELINE config 4 is 10.24 GB, 3.6 % of one MI355X's 288 GB); ids int64 ``[capacity]``.
+"""
+from __future__ import annotations
+
+import json
+import os
+import struct
+import time
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_MAGIC = b"AMDRECIX1"
+INDEX_TYPES = ("Flat", "IVF", "IVFPQ", "HNSW")
+
+
+class _Handle:
+    """The attributes of a faiss index object that the reference touches
+    (``index.ntotal``, ``index.is_trained``, ``index.nprobe``: faiss_retrieval.py:90, :127, :150)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    @property
+    def ntotal(self):
+        return self._o._n
+
+    @property
+    def is_trained(self):
+        return self._o._trained
+
+    @property
+    def nprobe(self):
+        if self._o.index_type != "IVF":
+            raise AttributeError("nprobe")
+        return self._o.nprobe
+
+    @nprobe.setter
+    def nprobe(self, v):
+        self._o.nprobe = int(v)
+
+
+class FAISSIndex:
+    def __init__(self, dimension: int, index_type: str = "IVF", nlist: int = 100, nprobe: int = 10,
+                 use_gpu: bool = False, device=None, verbose: bool = False):
+        """``use_gpu`` is accepted for signature compatibility; the index always lives on the
+        HIP device (``device`` or the current one) - there is no CPU engine."""
+        self.dimension = int(dimension)
+        self.index_type = index_type
+        self.nlist = int(nlist)
+        self.nprobe = int(nprobe)
+        self.use_gpu = use_gpu
+        self.verbose = verbose
+        self.device = torch.device(device if device is not None else "cuda")
+        self._create_index()
+
+    # -- construction ---------------------------------------------------------------
+    def _create_index(self):
+        if self.index_type not in INDEX_TYPES:
+            raise ValueError(f"Unknown index type: {self.index_type}")          # :73
+        if self.index_type in ("IVFPQ", "HNSW"):
+            raise NotImplementedError(
+                f"{self.index_type} is outside the MI355X hot path (SURVEY.md §2 #12): use 'Flat' or 'IVF'")
+        if self.dimension % 4 or not (4 <= self.dimension <= 2048):
+            raise ValueError("dimension must be a multiple of 4 in [4, 2048]")
+        _lib.load()
+        self._xb = torch.empty((0, self.dimension), dtype=torch.float32, device=self.device)
+        self._ids = torch.empty((0,), dtype=torch.int64, device=self.device)
+        self._n = 0
+        self._identity = True          # ids == arange(n): remap is the identity
+        self._host_ids: Optional[list] = None   # only for non-integer ids
+        self._trained = self.index_type == "Flat"
+        self._ivf = None               # set by train() for IVF
+        self.index = _Handle(self)
+        self._log(f"Created {self.index_type} index with dimension {self.dimension}")
+
+    def _log(self, msg):
+        if self.verbose:
+            print(msg)
+
+    # -- helpers --------------------------------------------------------------------
+    def _to_device_f32(self, a) -> torch.Tensor:
+        """fp32 device COPY of the input (``astype('float32')`` at :114 / :146 copies)."""
+        if isinstance(a, torch.Tensor):
+            t = a.detach().to(device=self.device, dtype=torch.float32, copy=True)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.float32)).to(self.device)
+        if t.dim() != 2 or t.shape[1] != self.dimension:
+            raise ValueError(f"expected [n, {self.dimension}] embeddings, got {tuple(t.shape)}")
+        return t.contiguous()
+
+    def _normalize_(self, t: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        if t.shape[0] == 0:
+            return t
+        _lib.check(lib.amdrec_l2_normalize(_lib.ptr(t), t.stride(0), _lib.ptr(t), t.stride(0), t.shape[0],
+                                           self.dimension, _lib.stream_ptr(self.device)))
+        return t
+
+    def _reserve(self, n):
+        cap = self._xb.shape[0]
+        if n <= cap:
+            return
+        new_cap = max(n, int(cap * 1.5), 1024)
+        xb = torch.empty((new_cap, self.dimension), dtype=torch.float32, device=self.device)
+        ids = torch.empty((new_cap,), dtype=torch.int64, device=self.device)
+        if self._n:
+            xb[:self._n].copy_(self._xb[:self._n])
+            ids[:self._n].copy_(self._ids[:self._n])
+        self._xb, self._ids = xb, ids
+
+    # -- reference API ----------------------------------------------------------------
+    def train(self, embeddings):
+        """faiss_retrieval.py:83-95: trains the coarse quantizer of IVF; no-op for Flat."""
+        if self._trained:
+            return
+        t0 = time.time()
+        self._log(f"Training index on {len(embeddings)} samples...")
+        from . import ivf
+        self._ivf = ivf.IVFState.train(self._to_device_f32(embeddings), self.nlist)
+        self._trained = True
+        self._log(f"Index trained in {time.time() - t0:.2f}s")
+
+    def add(self, embeddings, ad_ids: Optional[List] = None):
+        """faiss_retrieval.py:97-127."""
+        if not self._trained:
+            self.train(embeddings)                                   # :107-108 (un-normalised input)
+        t0 = time.time()
+        x = self._normalize_(self._to_device_f32(embeddings))        # :114-115
+        m = x.shape[0]
+        self._reserve(self._n + m)
+        self._xb[self._n:self._n + m].copy_(x)                       # :118
+        if ad_ids is None:                                           # :121-122
+            new_ids = torch.arange(self._n, self._n + m, dtype=torch.int64, device=self.device)
+            if self._host_ids is not None:
+                self._host_ids.extend(range(self._n, self._n + m))
+        else:
+            if len(ad_ids) != m:
+                raise ValueError("len(ad_ids) != len(embeddings)")
+            try:
+                arr = np.asarray(ad_ids)
+                if arr.dtype.kind not in "iu":
+                    raise TypeError
+                new_ids = torch.from_numpy(arr.astype(np.int64)).to(self.device)
+                ident = bool(m == 0 or (arr[0] == self._n and np.array_equal(arr, np.arange(self._n, self._n + m))))
+                self._identity = self._identity and ident
+                if self._host_ids is not None:
+                    self._host_ids.extend(arr.tolist())
+            except TypeError:
+                # arbitrary Python objects as ids: keep them on the host (plumbing, not compute)
+                if self._host_ids is None:
+                    self._host_ids = self._ids[:self._n].tolist()
+                self._host_ids.extend(list(ad_ids))
+                self._identity = False
+                new_ids = torch.full((m,), -1, dtype=torch.int64, device=self.device)
+        self._ids[self._n:self._n + m].copy_(new_ids)                # :123
+        if self._ivf is not None:
+            self._ivf.append(x, self._n)
+        self._n += m
+        self._log(f"Added embeddings in {time.time() - t0:.2f}s")
+        self._log(f"Total index size: {self._n}")
+
+    @property
+    def id_map(self) -> list:
+        if self._host_ids is not None:
+            return self._host_ids
+        return self._ids[:self._n].tolist()
+
+    def search_device(self, queries: torch.Tensor, k: int, normalize: bool = True,
+                      return_positions: bool = False):
+        """Device-to-device search, asynchronous on the current stream.
+        -> (ids int64 [nq,k], scores float32 [nq,k]) on the device."""
+        q = _lib.require_gpu(queries, "queries")
+        q = q.to(dtype=torch.float32, copy=True) if normalize else q
+        if q.dim() != 2 or q.shape[1] != self.dimension:
+            raise ValueError(f"expected [nq, {self.dimension}] queries, got {tuple(q.shape)}")
+        q = q.contiguous()
+        if normalize:
+            self._normalize_(q)                                      # :146-147
+        nq = q.shape[0]
+        scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        pos = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        if self.index_type == "IVF":
+            self._ivf.search(self._xb, self._n, q, k, self.nprobe, scores, pos)
+        else:
+            flat_search(self._xb, self._n, q, k, scores, pos)
+        if return_positions or self._identity:
+            # identity map: id == position for filled slots; unfilled (-1) slots map to
+            # id_map[-1] in the reference (:159) - reproduce that too
+            if return_positions:
+                return pos, scores
+            if self._n:
+                pos = torch.where(pos < 0, pos + self._n, pos)
+            return pos, scores
+        lib = _lib.load()
+        ids = torch.empty_like(pos)
+        _lib.check(lib.amdrec_remap_ids(_lib.ptr(pos), _lib.ptr(self._ids), self._n, _lib.ptr(ids), pos.numel(),
+                                        _lib.stream_ptr(self.device)))
+        return ids, scores
+
+    def search(self, query_embeddings, k: int = 100, return_distances: bool = True):
+        """faiss_retrieval.py:129-166.  numpy in, numpy out: (ad_ids, distances)."""
+        q = self._to_device_f32(query_embeddings)
+        t0 = time.time()
+        if self._host_ids is not None:
+            pos, scores = self.search_device(q, k, normalize=True, return_positions=True)
+            idm = np.asarray(self._host_ids, dtype=object)
+            ad_ids = idm[pos.cpu().numpy()]                          # pos == -1 -> id_map[-1]
+        else:
+            ids, scores = self.search_device(q, k, normalize=True)
+            ad_ids = ids.cpu().numpy()
+        distances = scores.cpu().numpy()
+        self._log(f"Search completed in {(time.time() - t0) * 1000:.2f}ms for {len(q)} queries")
+        if return_distances:
+            return ad_ids, distances
+        return ad_ids
+
+    def batch_search(self, query_embeddings, k: int = 100, batch_size: int = 1000):
+        """faiss_retrieval.py:168-194."""
+        all_ids, all_d = [], []
+        for i in range(0, len(query_embeddings), batch_size):
+            ids, d = self.search(query_embeddings[i:i + batch_size], k)
+            all_ids.append(ids)
+            all_d.append(d)
+        return np.vstack(all_ids), np.vstack(all_d)
+
+    # -- persistence: own format (faiss' write_index binary is unreadable without faiss) --
+    def save(self, filepath: str):
+        """faiss_retrieval.py:196-221: index file + ``<path>.metadata`` sidecar.  The index file is
+        ``AMDRECIX1 | u64 header_len | json header | raw arrays``; the sidecar is JSON with the
+        reference's metadata fields (dimension, index_type, nlist, nprobe) - never pickle."""
+        d = os.path.dirname(os.path.abspath(filepath))
+        os.makedirs(d, exist_ok=True)
+        arrays = [("xb", self._xb[:self._n].cpu().numpy()), ("ids", self._ids[:self._n].cpu().numpy())]
+        if self._ivf is not None:
+            arrays += self._ivf.export_arrays()
+        header = {"dimension": self.dimension, "index_type": self.index_type, "nlist": self.nlist,
+                  "nprobe": self.nprobe, "ntotal": self._n, "identity_ids": self._identity,
+                  "arrays": [{"name": n, "dtype": str(a.dtype), "shape": list(a.shape)} for n, a in arrays]}
+        if self._host_ids is not None:
+            header["host_ids"] = [str(x) for x in self._host_ids]
+        hj = json.dumps(header).encode()
+        with open(filepath, "wb") as f:
+            f.write(_MAGIC)
+            f.write(struct.pack("<Q", len(hj)))
+            f.write(hj)
+            for _, a in arrays:
+                f.write(np.ascontiguousarray(a).tobytes())
+        with open(filepath + ".metadata", "w") as f:
+            json.dump({k: header[k] for k in ("dimension", "index_type", "nlist", "nprobe", "ntotal")}, f)
+        self._log(f"Index saved to {filepath}")
+
+    def load(self, filepath: str):
+        """faiss_retrieval.py:223-245."""
+        with open(filepath, "rb") as f:
+            if f.read(len(_MAGIC)) != _MAGIC:
+                raise ValueError(f"{filepath} is not an amdrec index file")
+            (hl,) = struct.unpack("<Q", f.read(8))
+            header = json.loads(f.read(hl).decode())
+            arrays = {}
+            for spec in header["arrays"]:
+                dt = np.dtype(spec["dtype"])
+                cnt = int(np.prod(spec["shape"])) if spec["shape"] else 1
+                arrays[spec["name"]] = np.frombuffer(f.read(cnt * dt.itemsize), dtype=dt).reshape(spec["shape"])
+        self.dimension = header["dimension"]
+        self.index_type = header["index_type"]
+        self.nlist = header["nlist"]
+        self.nprobe = header["nprobe"]
+        self._create_index()
+        n = header["ntotal"]
+        self._reserve(n)
+        self._xb[:n].copy_(torch.from_numpy(arrays["xb"].copy()))
+        self._ids[:n].copy_(torch.from_numpy(arrays["ids"].copy()))
+        self._n = n
+        self._identity = header["identity_ids"]
+        self._host_ids = header.get("host_ids")
+        if self.index_type == "IVF":
+            from . import ivf
+            self._ivf = ivf.IVFState.from_arrays(arrays, self.device)
+            self._trained = True
+        self._log(f"Index loaded from {filepath}")
+        self._log(f"Index size: {self._n}")
+
+    def get_stats(self):
+        """faiss_retrieval.py:247-256."""
+        return {"index_type": self.index_type, "dimension": self.dimension, "num_vectors": self._n,
+                "is_trained": self._trained, "nlist": self.nlist, "nprobe": self.nprobe}
+
+
+def flat_search(xb: torch.Tensor, n: int, q: torch.Tensor, k: int, out_scores: torch.Tensor,
+                out_pos: torch.Tensor, pos_offset: int = 0, n_fixup: Optional[torch.Tensor] = None):
+    """amdrec_flat_search on device tensors (rows of xb[:n] and q already L2-normalised)."""
+    lib = _lib.load()
+    dev = q.device
+    if q.shape[0] == 0:
+        return
+    nbytes = _lib.C.c_size_t(0)
+    _lib.check(lib.amdrec_flat_search_workspace(q.shape[0], n, k, _lib.C.byref(nbytes)))
+    ws = _lib.WORKSPACE.get(nbytes.value, dev)
+    _lib.check(lib.amdrec_flat_search(
+        _lib.ptr(xb), n, xb.stride(0) if xb.dim() == 2 and xb.shape[0] > 0 else xb.shape[-1], xb.shape[-1],
+        _lib.ptr(q), q.shape[0], q.stride(0), k, pos_offset, _lib.ptr(out_scores), _lib.ptr(out_pos),
+        _lib.ptr(ws), ws.numel(), _lib.ptr(n_fixup), _lib.stream_ptr(dev)))

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Build libamdrec.so (hand-written HIP for gfx950 + the C ABI) in-tree with hipcc.
+
+    python movie-recommender-demo_amd/build.py [--force] [--verbose]
+
+Output: movie-recommender-demo_amd/lib/libamdrec.so (git-ignored, travels with gpurun).
+hipcc cross-compiles gfx950 without a GPU.  One translation unit per source, compiled in
+parallel, relinked only when something changed.
+"""
+import argparse
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT, "libamdrec.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(p.encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _compile(src, verbose):
+    obj = os.path.join(OUT, src + ".o")
+    cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return src, obj, r
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "amdrec.h"))
+    srcs = _sources()
+    stamp = os.path.join(OUT, "build.sha256")
+    digest = _digest(headers + [os.path.join(CSRC, s) for s in srcs])
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return LIB
+    objs = []
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        for src, obj, r in ex.map(lambda s: _compile(s, verbose), srcs):
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError(f"hipcc failed on {src}")
+            if verbose and r.stderr.strip():
+                sys.stderr.write(r.stderr)
+            objs.append(obj)
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("link failed")
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(a.force, a.verbose))

@@ -1,0 +1,253 @@
+// fp32-MFMA "NT" GEMM mainloop for gfx950:   C[p][q] = sum_k P[p][k] * Q[q][k]
+//
+// Every GEMM-shaped op of the hot path (inner-product search, tower MLPs, ranker layers)
+// is this loop with a different operand loader and epilogue.  Both operands are
+// K-contiguous ("row of P dot row of Q").
+//
+// Hardware mapping (MI355X_MICROARCH.md / cdna_hip_programming.md §3 "FP32-input MFMA"):
+//  * v_mfma_f32_32x32x2_f32: exact fp32 (fmaf chain), 64 FLOP/clk/SIMD = the fp32 peak.
+//    A operand: lane l holds P[p = l&31][k = l>>5]; B operand: Q[q = l&31][k = l>>5].
+//    C/D: lane&31 = q column, row p = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+//  * 512-thread workgroups = 8 waves = 2 per SIMD, arranged WP x WQ; each wave owns
+//    TP x TQ tiles of 32x32 (acc in VGPRs: 16*TP*TQ per lane).
+//  * Operands are staged global -> registers -> LDS in full 128-byte row segments
+//    (BK = 32 floats), double-buffered, one barrier per K-step.  The LDS image is
+//    [row][32 floats] with the 16-byte chunk index XOR-swizzled by (row>>1)&7 so that a
+//    fragment read (ds_read_b128, 16-lane groups of distinct rows, same chunk) is
+//    bank-conflict free (guide §2 LDS, T2).
+//  * Fragment k-order: a lane's ds_read_b128 returns 4 consecutive k (lane half h reads
+//    chunk 2c+h); MFMA step s of chunk pair c therefore multiplies k = 8c+4h+s.  P and Q
+//    use the same permutation, so the sum over k is complete; only the fp32 summation
+//    order differs from a sequential loop.
+#pragma once
+#include "common.hpp"
+
+namespace amdrec {
+
+constexpr int BK = 32;          // floats per K-step
+constexpr int NTHREADS = 512;   // 8 waves
+
+__device__ __forceinline__ int lds_slot(int row, int chunk) {
+    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);   // float index
+}
+
+// ---- operand loaders: load(row, k) -> 4 consecutive k (k % 4 == 0), zeros outside ----
+
+// Dense row-major matrix [rows][ld] with K valid columns.  ld % 4 == 0, base 16-B aligned.
+// Optional strided-block row map (sampling): row r -> (r / G) * S + r % G, G = 1 << gshift.
+struct DenseRows {
+    const float* base;
+    long long rows;      // number of valid *mapped* rows (actual row < rows)
+    int ld;
+    int K;
+    int gshift;          // log2(G); blocks of G consecutive rows
+    long long gstride;   // S: distance (rows) between consecutive blocks; == G for identity
+    __device__ __forceinline__ long long map(long long r) const {
+        return ((r >> gshift) * gstride) + (r & ((1ll << gshift) - 1));
+    }
+    __device__ __forceinline__ f32x4 load(long long r, int k) const {
+        long long a = map(r);
+        if (a < rows && k < K) return *reinterpret_cast<const f32x4*>(base + a * ld + k);
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+// Concatenation of categorical-embedding rows and a numerical tail, gathered on the fly
+// (EmbeddingLayer.forward two_tower_model.py:33-49; embed_features transformer_ranker.py:310-330):
+//   k in [0, F*E)         -> table[off[f] + cat[row][f]][k % E],  f = k / E   (E % 4 == 0)
+//   k in [F*E, F*E + n_num) -> num[row][k - F*E]
+// cat is int64 [rows][F] (the reference casts .long()); a second categorical source lets the
+// ranker read user features (F0 columns) and ad features (F - F0 columns) from two arrays.
+struct EmbConcatRows {
+    const float* tables;        // all feature tables back to back, [sum(card)][E]
+    const int* off;             // [F] first row of feature f in `tables`
+    const long long* cat0;      // [rows][F0]
+    const long long* cat1;      // [rows][F - F0] or nullptr
+    const long long* rowmap1;   // optional: cat1 row = rowmap1[row] (candidate id -> ad table row)
+    const float* num;           // [rows][n_num] or nullptr
+    const int* num_rowdiv;      // unused (reserved)
+    long long rows;
+    int F, F0, E, eshift;       // E == 1 << eshift
+    int n_num;
+    int cat0_rowdiv;            // cat0/num row = row / cat0_rowdiv (user row broadcast over candidates)
+    __device__ __forceinline__ f32x4 load(long long r, int k) const {
+        f32x4 z{0.f, 0.f, 0.f, 0.f};
+        if (r >= rows) return z;
+        int fe = F << eshift;
+        if (k < fe) {
+            int f = k >> eshift;
+            long long idx;
+            if (f < F0) {
+                idx = cat0[(r / cat0_rowdiv) * F0 + f];
+            } else {
+                long long r1 = rowmap1 ? rowmap1[r] : r;
+                idx = cat1[r1 * (F - F0) + (f - F0)];
+            }
+            return *reinterpret_cast<const f32x4*>(tables + (((long long)off[f] + idx) << eshift) +
+                                                   (k & ((1 << eshift) - 1)));
+        }
+        int j = k - fe;
+        if (num == nullptr || j >= n_num) return z;
+        const float* p = num + (r / cat0_rowdiv) * n_num;
+        z[0] = p[j];
+        if (j + 1 < n_num) z[1] = p[j + 1];
+        if (j + 2 < n_num) z[2] = p[j + 2];
+        if (j + 3 < n_num) z[3] = p[j + 3];
+        return z;
+    }
+};
+
+// ---- block -> tile mapping -----------------------------------------------------------
+// One operand is "small" (few tiles: query blocks, output-feature blocks), the other is
+// streamed.  Blocks that share a streamed tile differ only in the small index; give them
+// ids b, b+8, b+16, ... so that (observed round-robin placement, speed only) they land on
+// one XCD and the streamed tile is fetched from HBM once and re-read from that XCD's L2.
+struct TileMap {
+    int tiles_small, tiles_big;
+    __device__ __forceinline__ bool get(int bid, int& small, int& big) const {
+        int per = 8 * tiles_small;
+        int group = bid / per, within = bid - group * per;
+        small = within >> 3;
+        big = group * 8 + (within & 7);
+        return big < tiles_big;
+    }
+    int grid() const { return ((tiles_big + 7) / 8) * 8 * tiles_small; }
+};
+
+template <int WP_, int WQ_, int TP_, int TQ_>
+struct Shape {
+    static constexpr int WP = WP_, WQ = WQ_, TP = TP_, TQ = TQ_;
+    static constexpr int BP = WP * TP * 32, BQ = WQ * TQ * 32;
+    static constexpr int STAGE_FLOATS = (BP + BQ) * BK;
+    static constexpr size_t LDS_BYTES = 2ull * STAGE_FLOATS * sizeof(float);
+    static_assert(WP * WQ == 8, "8 waves per workgroup");
+};
+
+// Accumulator tile set of one wave and where it sits in the output.
+template <int TP, int TQ>
+struct Acc {
+    f32x16 v[TP][TQ];
+    int p0, q0;   // global p / q index of the wave's first row / column
+    // p index of register r in tile tp, q index of this lane in tile tq
+    __device__ __forceinline__ int p(int tp, int r, int lane) const {
+        return p0 + tp * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ __forceinline__ int q(int tq, int lane) const { return q0 + tq * 32 + (lane & 31); }
+};
+
+// The mainloop.  P_IS_SMALL: which operand the TileMap's "small" index addresses.
+template <class S, bool P_IS_SMALL, class LoadP, class LoadQ, class Epi>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(LoadP lp, LoadQ lq, Epi epi, int ksteps,
+                                                           TileMap tm) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TP = S::TP, TQ = S::TQ, BP = S::BP, BQ = S::BQ;
+    int small, big;
+    if (!tm.get(blockIdx.x, small, big)) return;
+    const int tile_p = P_IS_SMALL ? small : big;
+    const int tile_q = P_IS_SMALL ? big : small;
+    const long long prow0 = (long long)tile_p * BP;
+    const long long qrow0 = (long long)tile_q * BQ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wp = wave / S::WQ, wq = wave % S::WQ;
+
+    // staging assignment: thread handles 16-B chunk (tid&7) of rows (tid>>3) + 64*u
+    const int srow = tid >> 3, schunk = tid & 7;
+    constexpr int NP = (BP + 63) / 64, NQ = (BQ + 63) / 64;
+    f32x4 rp[NP], rq[NQ];
+
+    auto stage_load = [&](int kt) {
+        const int k = kt * BK + schunk * 4;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            int r = srow + 64 * u;
+            if (BP % 64 == 0 || r < BP) rp[u] = lp.load(prow0 + r, k);
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            int r = srow + 64 * u;
+            if (BQ % 64 == 0 || r < BQ) rq[u] = lq.load(qrow0 + r, k);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float* sp = smem + buf * S::STAGE_FLOATS;
+        float* sq = sp + BP * BK;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            int r = srow + 64 * u;
+            if (BP % 64 == 0 || r < BP) *reinterpret_cast<f32x4*>(sp + lds_slot(r, schunk)) = rp[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            int r = srow + 64 * u;
+            if (BQ % 64 == 0 || r < BQ) *reinterpret_cast<f32x4*>(sq + lds_slot(r, schunk)) = rq[u];
+        }
+    };
+
+    Acc<TP, TQ> acc;
+    acc.p0 = (int)prow0 + wp * TP * 32;   // NOTE: int indices: streamed dims stay < 2^31 rows
+    acc.q0 = (int)qrow0 + wq * TQ * 32;
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    const int frow = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < ksteps; ++kt) {
+        const bool more = kt + 1 < ksteps;
+        if (more) stage_load(kt + 1);
+        const float* sp = smem + (kt & 1) * S::STAGE_FLOATS + (wp * TP * 32) * BK;
+        const float* sq = smem + (kt & 1) * S::STAGE_FLOATS + BP * BK + (wq * TQ * 32) * BK;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 a[TP], b[TQ];
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(sp + lds_slot(i * 32 + frow, 2 * c + fh));
+#pragma unroll
+            for (int j = 0; j < TQ; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(sq + lds_slot(j * 32 + frow, 2 * c + fh));
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TP; ++i)
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j)
+                        acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s],
+                                                                           acc.v[i][j], 0, 0, 0);
+        }
+        if (more) stage_store((kt + 1) & 1);
+        __syncthreads();
+    }
+    epi(acc, smem);
+}
+
+template <class S, bool P_IS_SMALL, class LoadP, class LoadQ, class Epi>
+inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, int K, long long p_rows,
+                              long long q_rows, hipStream_t stream) {
+    auto kern = gemm_nt_kernel<S, P_IS_SMALL, LoadP, LoadQ, Epi>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    TileMap tm;
+    int tiles_p = (int)((p_rows + S::BP - 1) / S::BP), tiles_q = (int)((q_rows + S::BQ - 1) / S::BQ);
+    tm.tiles_small = P_IS_SMALL ? tiles_p : tiles_q;
+    tm.tiles_big = P_IS_SMALL ? tiles_q : tiles_p;
+    if (tm.tiles_small <= 0 || tm.tiles_big <= 0) return hipSuccess;
+    int ksteps = (K + BK - 1) / BK;
+    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(NTHREADS), S::LDS_BYTES, stream, lp, lq, epi, ksteps, tm);
+    return hipGetLastError();
+}
+
+}  // namespace amdrec

@@ -1,0 +1,427 @@
+// Exact inner-product top-k over a flat corpus (replaces faiss IndexFlatIP.search as called
+// from FAISSIndex.search, faiss_retrieval.py:155).
+//
+// Algorithm ("threshold-prefiltered exact top-k"), all on device, no host sync:
+//   1. sample pass : scores of every query against an evenly spaced subset of corpus tiles
+//                    (fp32 MFMA GEMM, dense store)                     ~3 % of the corpus
+//   2. threshold   : per query the r-th largest sample score tau_q (LDS radix select); the
+//                    expected number of corpus rows with score >= tau_q is ~max(2k, k+1500)
+//   3. filter pass : fp32 MFMA GEMM over the whole corpus; the epilogue appends
+//                    (score, row) keys with score >= tau_q to a per-query candidate list
+//   4. finalize    : per query, if k <= count <= capacity the exact top-k is inside the
+//                    list (every row >= tau is there) -> bitonic sort of 64-bit keys in LDS
+//   5. fix-up      : queries whose count fell outside [k, capacity] (adversarial order,
+//                    massive ties) are re-done by an exact streaming scan (16 slices per
+//                    query, running threshold) + merge.  Blocks of healthy queries exit at once.
+// The result is exact for every input; only the speed depends on the data.
+// Order: score descending, equal scores -> lower row first (deterministic).
+#include "gemm_core.hpp"
+#include "../../include/amdrec.h"
+
+namespace amdrec {
+
+constexpr int CAND_CAP = 8192;     // candidate keys per query (64 KB LDS sort)
+constexpr int SAMPLE_RANK = 64;    // r
+constexpr int KMAX = 2048;
+constexpr int FIX_BUF = 4096;      // fix-up scan buffer (keys)
+constexpr int SAMPLE_G = 256;      // rows per sample block (== BP of every search shape / divides it)
+
+// ---- epilogues (lane <-> query, registers <-> corpus rows) ---------------------------
+struct EpiStoreScores {
+    float* out;          // [nq][ld]
+    long long ld;
+    int nq;
+    long long n_sample;  // sample rows
+    DenseRows map;       // to test validity of the mapped row
+    template <int TP, int TQ>
+    __device__ void operator()(Acc<TP, TQ>& acc, float*) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            int q = acc.q(j, lane);
+            if (q >= nq) continue;
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int p = acc.p(i, 4 * g, lane);   // 4 consecutive rows p..p+3
+                    if (p >= n_sample) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float s = acc.v[i][j][4 * g + e];
+                        v[e] = (map.map(p + e) < map.rows) ? s : -INFINITY;
+                    }
+                    *reinterpret_cast<f32x4*>(out + (long long)q * ld + p) = v;
+                }
+        }
+    }
+};
+
+struct EpiFilter {
+    const float* tau;            // [nq]
+    unsigned long long* cand;    // [nq][cap]
+    int* cnt;                    // [nq]
+    int cap, nq;
+    long long nrows;
+    template <int TP, int TQ>
+    __device__ void operator()(Acc<TP, TQ>& acc, float*) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            int q = acc.q(j, lane);
+            float t = (q < nq) ? tau[q] : INFINITY;
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = acc.v[i][j][r];
+                    int p = acc.p(i, r, lane);
+                    if (s >= t && p < nrows) {
+                        int pos = atomicAdd(&cnt[q], 1);
+                        if (pos < cap) cand[(long long)q * cap + pos] = make_key(s, (uint32_t)p);
+                    }
+                }
+        }
+    }
+};
+
+// ---- block-wide helpers -------------------------------------------------------------
+// Find, scanning bins from the top, the bin that holds the r-th largest element.
+// hist[NB] in LDS; returns bin and updates r to the rank inside that bin.  All threads call.
+template <int NB, int NT>
+__device__ int find_bin_desc(const int* hist, int& r, int* scratch /*[NT+2]*/) {
+    constexpr int PER = NB / NT;
+    const int tid = threadIdx.x;
+    int local = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) local += hist[tid * PER + i];
+    scratch[tid] = local;
+    __syncthreads();
+    // serial suffix over NT partial sums by one wave-lane (NT <= 512: cheap)
+    if (tid == 0) {
+        int above = 0, found = -1, rr = r;
+        for (int t = NT - 1; t >= 0; --t) {
+            if (above + scratch[t] >= rr) { found = t; break; }
+            above += scratch[t];
+        }
+        int bin = -1;
+        if (found >= 0) {
+            for (int i = PER - 1; i >= 0; --i) {
+                int h = hist[found * PER + i];
+                if (above + h >= rr) { bin = found * PER + i; break; }
+                above += h;
+            }
+        }
+        scratch[NT] = bin;
+        scratch[NT + 1] = rr - above;
+    }
+    __syncthreads();
+    int bin = scratch[NT];
+    r = scratch[NT + 1];
+    __syncthreads();
+    return bin;
+}
+
+// r-th largest of S[q][0..n) -> tau[q]   (NaN counts as lowest; fewer than r values -> -inf)
+__global__ __launch_bounds__(256) void kth_largest_kernel(const float* S, long long ld, long long n, int r,
+                                                          float* tau) {
+    __shared__ int hist[2048];
+    __shared__ int scratch[258];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* row = S + (long long)q * ld;
+    uint32_t prefix = 0, pmask = 0;
+    int rr = r;
+    bool ok = n >= r;
+    const int shifts[3] = {21, 10, 0};
+    const int bits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3 && ok; ++pass) {
+        for (int i = tid; i < 2048; i += 256) hist[i] = 0;
+        __syncthreads();
+        const uint32_t bm = (1u << bits[pass]) - 1;
+        for (long long i = tid; i < n; i += 256) {
+            float v = row[i];
+            uint32_t key = (v == v) ? f32_orderable(v) : 0u;
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & bm], 1);
+        }
+        __syncthreads();
+        int bin = find_bin_desc<2048, 256>(hist, rr, scratch);
+        if (bin < 0) { ok = false; break; }
+        prefix |= (uint32_t)bin << shifts[pass];
+        pmask |= bm << shifts[pass];
+    }
+    if (tid == 0) tau[q] = ok ? f32_from_orderable(prefix) : -INFINITY;
+}
+
+// Bitonic sort of P (power of two) 64-bit keys in LDS, descending.  All threads call.
+__device__ void bitonic_desc(unsigned long long* buf, int P) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int sz = 2; sz <= P; sz <<= 1) {
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = tid; i < P; i += nt) {
+                int j = i ^ st;
+                if (j > i) {
+                    unsigned long long a = buf[i], b = buf[j];
+                    bool desc = (i & sz) == 0;
+                    if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ inline void write_result(const unsigned long long* buf, int have, int k, long long q, float* outD,
+                                    long long* outI, long long pos_offset) {
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        unsigned long long key = (i < have) ? buf[i] : 0ull;
+        bool valid = key != 0ull;
+        outD[q * k + i] = valid ? key_score(key) : -INFINITY;
+        outI[q * k + i] = valid ? (long long)key_pos(key) + pos_offset : -1ll;
+    }
+}
+
+// step 4: sort each query's candidate list, or flag it for the fix-up
+__global__ __launch_bounds__(512) void finalize_kernel(const unsigned long long* cand, const int* cnt, int cap,
+                                                       int k, long long nrows, int* fail, float* outD,
+                                                       long long* outI, long long pos_offset) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int q = blockIdx.x;
+    const int c = cnt[q];
+    const int need = (int)(nrows < k ? nrows : k);
+    if (c < need || c > cap) {
+        if (threadIdx.x == 0) { fail[q] = 1; atomicAdd(&fail[gridDim.x], 1); }
+        return;
+    }
+    int P = 2;
+    while (P < c) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = (i < c) ? cand[(long long)q * cap + i] : 0ull;
+    __syncthreads();
+    bitonic_desc(keys, P);
+    write_result(keys, c, k, q, outD, outI, pos_offset);
+}
+
+// step 5a: exact streaming scan of one corpus slice for a failed query
+__global__ __launch_bounds__(512) void fixup_scan_kernel(const float* X, long long ldx, long long nrows, int d,
+                                                         const float* Q, long long ldq, const int* fail,
+                                                         int k, int nslices, unsigned long long* scratch) {
+    __shared__ __attribute__((aligned(16))) unsigned long long buf[FIX_BUF];
+    __shared__ __attribute__((aligned(16))) float qv[2048];
+    __shared__ unsigned long long thr;
+    __shared__ int count;
+    const int q = blockIdx.y, s = blockIdx.x;
+    if (!fail[q]) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int NW = 8, U = 4;
+    for (int i = tid; i < d; i += 512) qv[i] = Q[(long long)q * ldq + i];
+    if (tid == 0) { thr = 0ull; count = 0; }
+    __syncthreads();
+    const long long per = (nrows + nslices - 1) / nslices;
+    const long long begin = (long long)s * per, end = (begin + per < nrows) ? begin + per : nrows;
+    const int d4 = d >> 2;
+    auto compact = [&]() {
+        int c = count;
+        for (int i = tid; i < FIX_BUF; i += 512) if (i >= c) buf[i] = 0ull;
+        __syncthreads();
+        bitonic_desc(buf, FIX_BUF);
+        if (tid == 0) {
+            int nc = c < k ? c : k;
+            count = nc;
+            thr = (nc == k) ? buf[k - 1] : 0ull;
+        }
+        __syncthreads();
+    };
+    for (long long row0 = begin; row0 < end; row0 += NW * U) {
+        float part[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            long long r = row0 + w * U + u;
+            float a = 0.f;
+            if (r < end) {
+                const f32x4* xr = reinterpret_cast<const f32x4*>(X + r * ldx);
+                for (int c = lane; c < d4; c += 64) {
+                    f32x4 x = xr[c];
+                    f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * c]);
+                    a += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+                }
+            }
+            part[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float a = part[u];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            long long r = row0 + w * U + u;
+            if (lane == 0 && r < end && a == a) {
+                unsigned long long key = make_key(a, (uint32_t)r);
+                if (key > thr) {
+                    int pos = atomicAdd(&count, 1);
+                    buf[pos] = key;   // pos < FIX_BUF guaranteed by the compaction rule below
+                }
+            }
+        }
+        __syncthreads();
+        // block-uniform decision: every thread reads `count` before anyone may change it again
+        if (__syncthreads_or(count > FIX_BUF - NW * U)) compact();
+    }
+    compact();
+    const int c = count;
+    unsigned long long* dst = scratch + ((long long)q * nslices + s) * k;
+    for (int i = tid; i < k; i += 512) dst[i] = (i < c) ? buf[i] : 0ull;
+}
+
+// step 5b: merge the slices of a failed query
+__global__ __launch_bounds__(512) void fixup_merge_kernel(const unsigned long long* scratch, const int* fail,
+                                                          int k, int nslices, float* outD, long long* outI,
+                                                          long long pos_offset) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int q = blockIdx.x;
+    if (!fail[q]) return;
+    const int total = k * nslices;
+    int P = 2;
+    while (P < total) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x)
+        keys[i] = (i < total) ? scratch[(long long)q * total + i] : 0ull;
+    __syncthreads();
+    bitonic_desc(keys, P);
+    write_result(keys, total < k ? total : k, k, q, outD, outI, pos_offset);
+}
+
+__global__ void fill_f32_kernel(float* p, long long n, float v) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---- plan ---------------------------------------------------------------------------
+struct SearchPlan {
+    long long n_sample;      // sample rows (multiple of SAMPLE_G), 0 => no sampling (tau = -inf)
+    long long gstride;       // rows between sample blocks
+    int rank;                // r
+    int nslices;             // fix-up slices
+    size_t off_tau, off_cnt, off_fail, off_cand, off_sample, off_fix, bytes;
+};
+
+static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl) {
+    long long nt = (nrows + SAMPLE_G - 1) / SAMPLE_G;
+    long long target = (2ll * k > k + 1500ll) ? 2ll * k : k + 1500ll;
+    if (nrows <= CAND_CAP) {
+        pl.n_sample = 0;                  // every row becomes a candidate
+        pl.gstride = SAMPLE_G;
+        pl.rank = 0;
+    } else {
+        long long n = (SAMPLE_RANK * nrows + target - 1) / target;
+        long long st = (n + SAMPLE_G - 1) / SAMPLE_G;       // sample tiles
+        if (st < 1) st = 1;
+        if (st > nt) st = nt;
+        long long stride = nt / st;
+        pl.gstride = stride * SAMPLE_G;
+        pl.n_sample = st * SAMPLE_G;
+        pl.rank = SAMPLE_RANK;
+    }
+    int ns = CAND_CAP / (k > 0 ? k : 1);
+    pl.nslices = ns < 1 ? 1 : (ns > 16 ? 16 : ns);
+    size_t o = 0;
+    pl.off_tau = o;    o = align_up(o + (size_t)nq * 4, 256);
+    pl.off_cnt = o;    o = align_up(o + (size_t)nq * 4, 256);
+    pl.off_fail = o;   o = align_up(o + (size_t)(nq + 1) * 4, 256);
+    pl.off_cand = o;   o = align_up(o + (size_t)nq * CAND_CAP * 8, 256);
+    pl.off_sample = o; o = align_up(o + (size_t)nq * (size_t)pl.n_sample * 4, 256);
+    pl.off_fix = o;    o = align_up(o + (size_t)nq * pl.nslices * k * 8, 256);
+    pl.bytes = o;
+    return 0;
+}
+
+template <class S>
+static hipError_t run_passes(const float* X, long long ldx, long long nrows, int d, const float* Q, long long ldq,
+                             int nq, const SearchPlan& pl, char* ws, hipStream_t st) {
+    DenseRows lq{Q, nq, (int)ldq, d, 30, 1ll << 30};
+    float* tau = reinterpret_cast<float*>(ws + pl.off_tau);
+    int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
+    if (pl.n_sample > 0) {
+        int gshift = 8;   // SAMPLE_G == 256
+        DenseRows lps{X, nrows, (int)ldx, d, gshift, pl.gstride};
+        float* S_ = reinterpret_cast<float*>(ws + pl.off_sample);
+        EpiStoreScores es{S_, pl.n_sample, nq, pl.n_sample, lps};
+        hipError_t e = launch_gemm<S, false>(lps, lq, es, d, pl.n_sample, nq, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kth_largest_kernel, dim3(nq), dim3(256), 0, st, S_, pl.n_sample, pl.n_sample, pl.rank,
+                           tau);
+    } else {
+        hipLaunchKernelGGL(fill_f32_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, tau, (long long)nq,
+                           -INFINITY);
+    }
+    DenseRows lp{X, nrows, (int)ldx, d, 30, 1ll << 30};
+    EpiFilter ef{tau, reinterpret_cast<unsigned long long*>(ws + pl.off_cand), cnt, CAND_CAP, nq, nrows};
+    return launch_gemm<S, false>(lp, lq, ef, d, nrows, nq, st);
+}
+
+}  // namespace amdrec
+
+using namespace amdrec;
+
+extern "C" int amdrec_flat_search_workspace(int64_t nq, int64_t nrows, int k, size_t* bytes) {
+    REQUIRE(bytes != nullptr, "bytes is null");
+    REQUIRE(nq >= 0 && nrows >= 0, "negative size");
+    REQUIRE(k >= 1 && k <= KMAX, "k=%d outside [1,%d]", k, KMAX);
+    SearchPlan pl;
+    make_plan(nq, nrows, k, pl);
+    *bytes = pl.bytes;
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld_corpus, int dim,
+                                  const float* queries, int64_t nq, int64_t ld_queries, int k,
+                                  int64_t pos_offset, float* out_scores, int64_t* out_pos, void* workspace,
+                                  size_t workspace_bytes, int* n_fixup, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    REQUIRE(k >= 1 && k <= KMAX, "k=%d outside [1,%d]", k, KMAX);
+    REQUIRE(dim >= 4 && dim % 4 == 0 && dim <= 2048, "dim=%d must be a multiple of 4 in [4,2048]", dim);
+    REQUIRE(nrows >= 0 && nrows < (1ll << 31) - 1024, "nrows out of range");
+    REQUIRE(nq >= 0 && nq < (1ll << 24), "nq out of range");
+    if (nq == 0) return AMDREC_OK;
+    REQUIRE((nrows == 0 || (ld_corpus >= dim && ld_corpus % 4 == 0)) && ld_queries >= dim && ld_queries % 4 == 0,
+            "leading dimensions must be >= dim and multiples of 4");
+    REQUIRE(corpus || nrows == 0, "corpus is null");
+    REQUIRE(queries && out_scores && out_pos, "null pointer");
+    REQUIRE(((uintptr_t)corpus % 16) == 0 && ((uintptr_t)queries % 16) == 0, "corpus/queries must be 16-byte aligned");
+    SearchPlan pl;
+    make_plan(nq, nrows, k, pl);
+    if (workspace_bytes < pl.bytes || workspace == nullptr)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", pl.bytes, workspace_bytes);
+    REQUIRE(((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
+    char* ws = reinterpret_cast<char*>(workspace);
+    int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
+    int* fail = reinterpret_cast<int*>(ws + pl.off_fail);
+    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));
+    HIP_TRY(hipMemsetAsync(fail, 0, (size_t)(nq + 1) * 4, st));
+
+    if (nrows > 0) {
+        hipError_t e;
+        if (nq > 128)      e = run_passes<Shape<2, 4, 4, 2>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
+        else if (nq > 64)  e = run_passes<Shape<4, 2, 2, 2>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
+        else if (nq > 32)  e = run_passes<Shape<8, 1, 2, 2>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
+        else               e = run_passes<Shape<8, 1, 2, 1>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
+        HIP_TRY(e);
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_merge_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
+        attr_done = true;
+    }
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + pl.off_cand);
+    unsigned long long* fix = reinterpret_cast<unsigned long long*>(ws + pl.off_fix);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, cand, cnt, CAND_CAP, k,
+                       (long long)nrows, fail, out_scores, (long long*)out_pos, (long long)pos_offset);
+    hipLaunchKernelGGL(fixup_scan_kernel, dim3(pl.nslices, (unsigned)nq), dim3(512), 0, st, corpus,
+                       (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, k,
+                       pl.nslices, fix);
+    hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, fix, fail, k,
+                       pl.nslices, out_scores, (long long*)out_pos, (long long)pos_offset);
+    HIP_TRY(hipGetLastError());
+    if (n_fixup) HIP_TRY(hipMemcpyAsync(n_fixup, fail + nq, sizeof(int), hipMemcpyDeviceToDevice, st));
+    return AMDREC_OK;
+}

@@ -1,0 +1,177 @@
+"""Parity of the HIP flat inner-product top-k (through the C ABI, via the FAISSIndex drop-in)
+against the CPU oracle.  Tolerances: tests/cases.py."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from amdrec import synth
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n, d, seed):
+    return synth.unit_corpus(n, d, seed=seed)
+
+
+def _both(xb, xq, k, ad_ids=None):
+    from amdrec.index import FAISSIndex
+    idx = FAISSIndex(xb.shape[1], index_type="Flat")
+    ora = oracle.search.FlatIndex(xb.shape[1])
+    idx.add(xb, ad_ids)
+    ora.add(xb, ad_ids)
+    ids, D = idx.search(xq, k)
+    rids, rD = ora.search(xq, k)
+    assert ids.dtype == np.int64 and D.dtype == np.float32 and ids.shape == (len(xq), k) == D.shape
+    return (ids, D), (rids, rD), ora
+
+
+def _check(got, ref, ora, xq, tau=cases.TOPK_TAU):
+    ids, D = got
+    rids, rD = ref
+    qn = oracle.search.normalize_l2(xq)
+    id2pos = {v: i for i, v in enumerate(ora.id_map)}
+
+    def scores_of(q, which):
+        rows = np.array([id2pos[int(i)] for i in which])
+        return (ora.xb[rows].astype(np.float64) @ qn[q].astype(np.float64)).astype(np.float32)
+
+    oracle.search.check_topk(rD, rids, D, ids, tau=tau, score_tol=cases.SCORE_ATOL, scores_of=scores_of)
+
+
+@pytest.mark.parametrize("n,nq,k", [(1000, 1, 10), (1000, 5, 500), (777, 33, 100), (4096, 70, 500),
+                                    (8192, 130, 37), (3000, 200, 1)])
+def test_small_corpus_all_candidates(n, nq, k):
+    xb, xq = _mk(n, 256, 1), _mk(nq, 256, 2)
+    got, ref, ora = _both(xb, xq, k)
+    _check(got, ref, ora, xq)
+
+
+@pytest.mark.parametrize("n,nq,k,d", [(50_000, 37, 500, 256), (120_001, 512, 500, 256), (30_000, 64, 2048, 128),
+                                      (20_000, 3, 10, 64), (9_000, 257, 100, 32)])
+def test_sampled_threshold_path(n, nq, k, d):
+    xb, xq = _mk(n, d, 3), _mk(nq, d, 4)
+    got, ref, ora = _both(xb, xq, k)
+    _check(got, ref, ora, xq)
+
+
+def test_unnormalised_inputs_are_renormalised_and_not_mutated():
+    rng = np.random.default_rng(0)
+    xb = (rng.standard_normal((5000, 256)) * 3).astype(np.float32)
+    xq = (rng.standard_normal((9, 256)) * 0.1).astype(np.float64)      # non-fp32 input
+    xb0, xq0 = xb.copy(), xq.copy()
+    got, ref, ora = _both(xb, xq, 50)
+    assert np.array_equal(xb, xb0) and np.array_equal(xq, xq0)
+    _check(got, ref, ora, xq)
+    assert np.all(got[1] <= 1.0 + 1e-5)
+
+
+def test_k_larger_than_corpus_pads_like_faiss():
+    xb, xq = _mk(100, 256, 5), _mk(4, 256, 6)
+    (ids, D), (rids, rD), _ = _both(xb, xq, 500)
+    assert np.all(np.isneginf(D[:, 100:])) and np.all(np.isneginf(rD[:, 100:]))
+    # unfilled slots: position -1 -> id_map[-1] (faiss_retrieval.py:159)
+    assert np.all(ids[:, 100:] == 99) and np.all(rids[:, 100:] == 99)
+    assert np.array_equal(ids[:, :100], rids[:, :100])
+
+
+def test_custom_ids_are_remapped():
+    xb, xq = _mk(3000, 256, 7), _mk(6, 256, 8)
+    ad_ids = (np.arange(3000) * 7 + 1000).tolist()
+    got, ref, ora = _both(xb, xq, 20, ad_ids)
+    _check(got, ref, ora, xq)
+    assert got[0].min() >= 1000
+
+
+def test_exact_ties_lower_position_wins():
+    """Duplicated rows (training_pipeline.py:523 indexes every interaction row, so duplicates
+    are expected): equal scores must come back lowest position first, bit-exact."""
+    base = _mk(2500, 256, 9)
+    xb = np.concatenate([base, base, base, base], axis=0)          # 10000 rows, 4 copies each
+    xq = _mk(16, 256, 10)
+    (ids, D), (rids, rD), _ = _both(xb, xq, 100)
+    assert np.array_equal(ids, rids)
+    assert np.abs(D - rD).max() <= cases.SCORE_ATOL
+    # within each group of equal scores ids ascend
+    for q in range(len(xq)):
+        same = D[q, 1:] == D[q, :-1]
+        assert np.all(ids[q, 1:][same] > ids[q, :-1][same])
+
+
+def test_massive_ties_take_the_exact_fixup_path():
+    """All rows identical: every score ties, the candidate list overflows -> fix-up scan."""
+    row = _mk(1, 256, 11)
+    xb = np.repeat(row, 20_000, axis=0)
+    xq = _mk(3, 256, 12)
+    (ids, D), (rids, rD), _ = _both(xb, xq, 500)
+    assert np.array_equal(ids, np.tile(np.arange(500), (3, 1)))
+    assert np.array_equal(ids, rids)
+    assert np.abs(D - rD).max() <= cases.SCORE_ATOL
+
+
+def test_adversarial_order_underflow_takes_fixup_path():
+    """Corpus sorted so that the best rows sit in one unsampled stretch and most sampled rows
+    score high for query 0: the sampled threshold is useless, the result must still be exact."""
+    rng = np.random.default_rng(13)
+    n, d = 40_000, 64
+    xq = _mk(2, d, 14)
+    xb = _mk(n, d, 15)
+    s = xb @ xq[0]
+    xb = xb[np.argsort(-s)]                                        # descending by query-0 score
+    got, ref, ora = _both(xb, xq, 500)
+    _check(got, ref, ora, xq)
+    assert np.array_equal(np.sort(got[0][0]), np.arange(500))
+
+
+def test_padded_leading_dimension_and_device_api():
+    from amdrec.index import flat_search
+    n, nq, k, d = 20_000, 50, 64, 96
+    xb, xq = _mk(n, d, 16), _mk(nq, d, 17)
+    big = torch.zeros((n, 128), dtype=torch.float32, device="cuda")
+    big[:, :d] = torch.from_numpy(xb).cuda()
+    qd = torch.from_numpy(xq).cuda()
+    D = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    I = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    nfix = torch.zeros(1, dtype=torch.int32, device="cuda")
+    flat_search(big[:, :d], n, qd, k, D, I, pos_offset=1_000_000, n_fixup=nfix)
+    rD, rI = oracle.search.flat_ip_search(xb, xq, k)
+    oracle.search.check_topk(rD, rI + 1_000_000, D.cpu().numpy(), I.cpu().numpy(), tau=cases.TOPK_TAU,
+                             score_tol=cases.SCORE_ATOL)
+    assert int(nfix.item()) == 0
+
+
+def test_empty_and_error_paths():
+    from amdrec import _lib
+    from amdrec.index import FAISSIndex
+    idx = FAISSIndex(256, index_type="Flat")
+    ids, D = idx.search(_mk(2, 256, 1), 5)                          # empty index
+    assert np.all(np.isneginf(D)) and ids.shape == (2, 5)
+    idx.add(_mk(10, 256, 2))
+    ids, D = idx.search(np.zeros((0, 256), np.float32), 5)         # no queries
+    assert ids.shape == (0, 5)
+    with pytest.raises(_lib.AmdrecError):
+        idx.search(_mk(1, 256, 3), 5000)                            # k > AMDREC_MAX_K
+    with pytest.raises(ValueError):
+        FAISSIndex(256, index_type="Annoy")
+
+
+def test_full_size_1m_against_oracle():
+    """BASELINE config 2 size: 1M x 256 corpus, 512 queries, k=500 (oracle on 24 of them)."""
+    from amdrec.index import FAISSIndex
+    xb = _mk(1_000_000, 256, 1234)
+    user, ad, nnum = synth.demo_dims()
+    xq = _mk(512, 256, 99)
+    idx = FAISSIndex(256, index_type="Flat")
+    idx.add(xb)
+    nfix = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ids, D = idx.search(xq, 500)
+    # size-independent properties on all 512 queries
+    assert np.all(np.diff(D, axis=1) <= 0)
+    assert all(len(set(r.tolist())) == 500 for r in ids)
+    recomputed = np.einsum("qkd,qd->qk", xb[ids[:64]].astype(np.float64), xq[:64].astype(np.float64))
+    assert np.abs(recomputed - D[:64]).max() <= cases.SCORE_ATOL
+    # oracle on a subset
+    sub = np.arange(0, 512, 22)[:24]
+    rD, rI = oracle.search.flat_ip_search(xb, xq[sub], 500)
+    oracle.search.check_topk(rD, rI, D[sub], ids[sub], tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
