@@ -46,6 +46,88 @@ int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld_corpus, in
                        int64_t* out_pos /*[nq][k]*/, void* workspace, size_t workspace_bytes,
                        int* n_fixup, void* stream);
 
+/* ---- two-tower encoders (eval mode) ------------------------------------------------------
+ * Replaces the ATen call chain of UserTower.forward / AdTower.forward
+ * (two_tower_model.py:98-121, :167-184): per-column embedding lookup + concat
+ * (EmbeddingLayer.forward :33-49) [+ numerical tail :113] -> (Linear, BatchNorm1d(eval), ReLU,
+ * Dropout(identity)) x n -> Linear -> F.normalize(p=2, dim=1).
+ * BatchNorm is folded into the preceding Linear by the host (exact in eval mode):
+ *   W' = W * g / sqrt(var + eps),  b' = (b - mean) * g / sqrt(var + eps) + beta.
+ * Weights are [out][ldw] row-major with K zero-padded to ldw (multiple of 32). */
+#define AMDREC_MAX_LAYERS 8
+#define AMDREC_MAX_TASKS 4
+
+typedef struct {
+    int32_t n_feat;              /* categorical columns (6 user / 20 ad) */
+    int32_t emb_dim;             /* 16; power of two >= 4 */
+    int32_t n_num;               /* numerical tail width (13 user / 0 ad) */
+    int32_t n_layers;            /* Linear layers incl. the output layer */
+    int32_t dims[AMDREC_MAX_LAYERS + 1]; /* dims[0] = n_feat*emb_dim + n_num, dims[l+1] = width of layer l */
+    int32_t ldw[AMDREC_MAX_LAYERS];
+    const float* tables;         /* all embedding tables back to back [sum(card)][emb_dim] */
+    const int32_t* table_off;    /* device [n_feat]: first row of column f */
+    const int32_t* cards;        /* device [n_feat]: cardinality of column f */
+    const float* w[AMDREC_MAX_LAYERS];
+    const float* b[AMDREC_MAX_LAYERS];
+} amdrec_tower_params;
+
+int amdrec_tower_workspace(const amdrec_tower_params* p /*host*/, int64_t rows, size_t* bytes /*host*/);
+/* cat int64 [rows][n_feat] (the reference casts .long()), num float32 [rows][n_num] or NULL,
+ * out float32 [rows][ld_out] unit rows.  bad_index_flag (device int, may be NULL) is set to 1 if
+ * any categorical index is outside [0, card) - torch raises IndexError there; the kernels clamp
+ * so nothing is read out of bounds. */
+int amdrec_tower_forward(const amdrec_tower_params* p /*host*/, const int64_t* cat, const float* num,
+                         int64_t rows, float* out, int64_t ld_out, int* bad_index_flag,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- TransformerRanker.forward (eval mode) -> logits --------------------------------------
+ * Replaces the ATen call chain of transformer_ranker.py:332-380.  With seq_len == 1 (:358) the
+ * 8-head attention is exactly W_o(W_v x + b_v) + b_o (softmax over one key == 1), so W_q / W_k
+ * are not parameters here.  pos[0] is folded into b_proj and cross weights are passed
+ * transposed ([out][in]) by the host. */
+typedef struct {
+    const float *w_v, *b_v, *w_o, *b_o;   /* [d_model][ldw_dm] */
+    const float *ln1_g, *ln1_b;
+    const float *w_1, *b_1;               /* [d_ff][ldw_dm] */
+    const float *w_2, *b_2;               /* [d_model][ldw_ff] */
+    const float *ln2_g, *ln2_b;
+    int32_t ldw_dm, ldw_ff;
+} amdrec_encoder_layer;
+
+typedef struct {
+    int32_t n_user_feat, n_ad_feat, emb_dim, n_num;
+    int32_t d_model, d_ff, n_layers, n_cross, n_tasks, head_h1, head_h2;
+    float ln_eps;
+    int32_t ldw_proj, ldw_cross, ldw_head1, ldw_head2;
+    const float* tables;            /* user tables then ad tables, [sum(card)][emb_dim] */
+    const int32_t* table_off;       /* device [n_user_feat + n_ad_feat] */
+    const int32_t* cards;           /* device [n_user_feat + n_ad_feat] */
+    const float* w_proj;            /* [d_model][ldw_proj], columns = [user emb | ad emb | numerical] */
+    const float* b_proj;            /* bias + positional_encoding[0,0,:] */
+    amdrec_encoder_layer layers[AMDREC_MAX_LAYERS];
+    const float* cross_wt[AMDREC_MAX_LAYERS];  /* cross_weights[i]^T : [out][ldw_cross] */
+    const float* cross_b[AMDREC_MAX_LAYERS];
+    const float* head_w1;           /* first Linear of all heads stacked: [n_tasks*head_h1][ldw_head1] */
+    const float* head_b1;
+    const float* head_w2[AMDREC_MAX_TASKS];   /* [head_h2][ldw_head2] */
+    const float* head_b2[AMDREC_MAX_TASKS];
+    const float* head_w3[AMDREC_MAX_TASKS];   /* [head_h2] */
+    const float* head_b3[AMDREC_MAX_TASKS];   /* [1] */
+} amdrec_ranker_params;
+
+int amdrec_ranker_workspace(const amdrec_ranker_params* p /*host*/, int64_t rows, size_t* bytes /*host*/);
+/* Row r of the batch uses user_cat/numerical row r / user_rowdiv (user_rowdiv = 1: one feature
+ * row per batch row as in forward(); = stage1_k: one user broadcast over its candidates, replacing
+ * Tensor.repeat at inference.py:241-242) and ad_cat row (ad_rowmap ? ad_rowmap[r] : r)
+ * (ad_rowmap = candidate ids into a resident ad-feature table: the lookup the reference stubs
+ * out at inference.py:244-248).  out_logits[t * ld_logits + r], t = ctr, engagement, revenue.
+ * n_user_rows / n_ad_rows = rows of user_cat / ad_cat (for index validation only). */
+int amdrec_ranker_forward(const amdrec_ranker_params* p /*host*/, const int64_t* user_cat,
+                          const float* numerical, int64_t user_rowdiv, const int64_t* ad_cat,
+                          const int64_t* ad_rowmap, int64_t rows, float* out_logits, int64_t ld_logits,
+                          int* bad_index_flag, int64_t n_user_rows, int64_t n_ad_rows, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* faiss.normalize_L2 (faiss_retrieval.py:115, :147): every row scaled by 1/||row||_2, rows of
  * zero norm left as they are.  out may alias in.  dim % 4 == 0. */
 int amdrec_l2_normalize(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t rows,

@@ -1,0 +1,147 @@
+"""Drop-in for the reference's ``TransformerRanker`` (transformer_ranker.py:207-415): same
+constructor, same parameter names/shapes (reference checkpoints load unchanged, including the
+dead W_q / W_k and the unused positional rows 1..49), eval-mode ``forward`` on libamdrec.
+
+``forward(user_categorical, ad_categorical, numerical, mask=None)`` keeps the reference's
+argument order (ad_categorical is SECOND, unlike TwoTowerModel) and returns the logits dict
+``{'ctr','engagement','revenue'}``.  ``mask`` is accepted and ignored: with the sequence
+length fixed at 1 (:358) softmax over a single key is 1.0 whatever the mask says.
+``score_candidates`` is the pipeline entry: one user row broadcast over its stage-1
+candidates, ad features gathered from a resident table by candidate id.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, weights
+
+
+class _Attention(nn.Module):
+    def __init__(self, d_model, num_heads, dropout):
+        super().__init__()
+        assert d_model % num_heads == 0
+        self.d_model, self.num_heads, self.d_k = d_model, num_heads, d_model // num_heads
+        for n in ("W_q", "W_k", "W_v", "W_o"):
+            setattr(self, n, nn.Linear(d_model, d_model))
+        self.dropout = nn.Dropout(dropout)
+
+
+class _FFN(nn.Module):
+    def __init__(self, d_model, d_ff, dropout):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(d_model, d_ff), nn.Linear(d_ff, d_model)
+        self.dropout = nn.Dropout(dropout)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, d_model, num_heads, d_ff, dropout):
+        super().__init__()
+        self.self_attention = _Attention(d_model, num_heads, dropout)
+        self.feed_forward = _FFN(d_model, d_ff, dropout)
+        self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout1, self.dropout2 = nn.Dropout(dropout), nn.Dropout(dropout)
+
+
+class _Cross(nn.Module):
+    def __init__(self, dim, num_crosses, dropout):
+        super().__init__()
+        self.num_crosses = num_crosses
+        self.cross_weights = nn.ParameterList([nn.Parameter(torch.randn(dim, dim)) for _ in range(num_crosses)])
+        self.cross_biases = nn.ParameterList([nn.Parameter(torch.randn(dim)) for _ in range(num_crosses)])
+        self.dropout = nn.Dropout(dropout)
+
+
+def _head(d_model, dropout):
+    return nn.Sequential(nn.Linear(d_model, 256), nn.ReLU(), nn.Dropout(dropout), nn.Linear(256, 64), nn.ReLU(),
+                         nn.Dropout(dropout), nn.Linear(64, 1))
+
+
+class TransformerRanker(nn.Module):
+    def __init__(self, user_feature_dims: Dict[str, int], ad_feature_dims: Dict[str, int], numerical_dim: int,
+                 embedding_dim: int = 32, d_model: int = 256, num_heads: int = 8, num_layers: int = 3,
+                 d_ff: int = 1024, max_seq_len: int = 50, dropout: float = 0.1, num_objectives: int = 3):
+        super().__init__()
+        self.user_embeddings = nn.ModuleDict({n: nn.Embedding(c, embedding_dim) for n, c in user_feature_dims.items()})
+        self.ad_embeddings = nn.ModuleDict({n: nn.Embedding(c, embedding_dim) for n, c in ad_feature_dims.items()})
+        total = (len(user_feature_dims) + len(ad_feature_dims)) * embedding_dim + numerical_dim
+        self.feature_projection = nn.Linear(total, d_model)
+        self.positional_encoding = nn.Parameter(torch.randn(1, max_seq_len, d_model))
+        self.transformer_layers = nn.ModuleList([_EncoderLayer(d_model, num_heads, d_ff, dropout)
+                                                 for _ in range(num_layers)])
+        self.feature_interaction = _Cross(d_model, 3, dropout)
+        self.prediction_heads = nn.ModuleDict({t: _head(d_model, dropout) for t in ("ctr", "engagement", "revenue")})
+        self.d_model = d_model
+        self.dropout = nn.Dropout(dropout)
+        self._user_names, self._ad_names, self._n_num = list(user_feature_dims), list(ad_feature_dims), numerical_dim
+        self._packed = None
+
+    # -- packing ----------------------------------------------------------------------
+    def invalidate(self):
+        self._packed = None
+
+    def _pack(self, device):
+        key = (str(device), tuple(p._version for p in self.parameters()))
+        if self._packed is None or self._packed[0] != key:
+            params, keep, tasks = weights.pack_ranker(self.state_dict(), self._user_names, self._ad_names,
+                                                      self._n_num, device)
+            self._packed = (key, params, keep, tasks)
+        return self._packed[1], self._packed[3]
+
+    def load_state_dict(self, state_dict, *a, **k):
+        r = super().load_state_dict(state_dict, *a, **k)
+        self.invalidate()
+        return r
+
+    # -- forward ----------------------------------------------------------------------
+    def _run(self, user_cat, numerical, user_rowdiv, ad_cat, ad_rowmap, rows, check_indices=True):
+        if self.training:
+            raise NotImplementedError("the HIP forward implements eval() semantics only; call .eval()")
+        dev = ad_cat.device
+        params, tasks = self._pack(dev)
+        lib = _lib.load()
+        logits = torch.empty((len(tasks), rows), dtype=torch.float32, device=dev)
+        if rows == 0:
+            return {t: logits[i] for i, t in enumerate(tasks)}
+        flag = torch.zeros(1, dtype=torch.int32, device=dev) if check_indices else None
+        nbytes = _lib.C.c_size_t(0)
+        _lib.check(lib.amdrec_ranker_workspace(_lib.C.byref(params), rows, _lib.C.byref(nbytes)))
+        ws = _lib.WORKSPACE.get(nbytes.value, dev)
+        _lib.check(lib.amdrec_ranker_forward(
+            _lib.C.byref(params), _lib.ptr(user_cat), _lib.ptr(numerical), user_rowdiv, _lib.ptr(ad_cat),
+            _lib.ptr(ad_rowmap), rows, _lib.ptr(logits), logits.stride(0), _lib.ptr(flag),
+            user_cat.shape[0], ad_cat.shape[0], _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+        if check_indices and int(flag.item()):
+            raise IndexError("index out of range in self")
+        return {t: logits[i] for i, t in enumerate(tasks)}
+
+    def forward(self, user_categorical, ad_categorical, numerical, mask: Optional[torch.Tensor] = None):
+        """transformer_ranker.py:332-380 -> {'ctr','engagement','revenue'}: logits [B]."""
+        uc = _lib.require_gpu(user_categorical, "user_categorical").long().contiguous()
+        ac = _lib.require_gpu(ad_categorical, "ad_categorical").long().contiguous()
+        nm = _lib.require_gpu(numerical, "numerical").to(torch.float32).contiguous()
+        B = uc.shape[0]
+        if uc.shape != (B, len(self._user_names)) or ac.shape != (B, len(self._ad_names)) or \
+                nm.shape != (B, self._n_num):
+            raise ValueError("bad feature shapes")
+        return self._run(uc, nm, 1, ac, None, B)
+
+    def score_candidates(self, user_categorical, numerical, candidate_rows, ad_table, check_indices=False):
+        """Pipeline form of inference.py:241-255: user u's features are broadcast over its
+        ``k = candidate_rows.shape[1]`` candidates (no .repeat), ad features are gathered from the
+        resident ``ad_table [N, n_ad_feat]`` by candidate row.  -> logits dict, each [U*k]."""
+        uc = _lib.require_gpu(user_categorical, "user_categorical").long().contiguous()
+        nm = _lib.require_gpu(numerical, "numerical").to(torch.float32).contiguous()
+        cand = _lib.require_gpu(candidate_rows, "candidate_rows", torch.int64).contiguous()
+        table = _lib.require_gpu(ad_table, "ad_table", torch.int64)
+        if not table.is_contiguous():
+            raise ValueError("ad_table must be contiguous")
+        U, k = cand.shape
+        if uc.shape[0] != U or nm.shape[0] != U:
+            raise ValueError("one user row per candidate list expected")
+        return self._run(uc, nm, k, table, cand.view(-1), U * k, check_indices)
+
+    def compute_loss(self, *a, **k):
+        raise NotImplementedError("training (transformer_ranker.py:382-415) is outside the MI355X hot path")

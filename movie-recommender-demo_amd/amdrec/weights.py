@@ -1,0 +1,186 @@
+"""Host-side weight preparation for libamdrec: fold eval-mode BatchNorm into the preceding
+Linear, zero-pad K to a multiple of 32, stack embedding tables, transpose cross weights,
+fold the positional row into the projection bias; build the ctypes parameter structs of
+include/amdrec.h.  Runs once per weight load (float64 on the host, rounded to float32)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+MAX_LAYERS = 8
+MAX_TASKS = 4
+_FP = C.c_void_p
+TASKS = ("ctr", "engagement", "revenue")
+
+
+class TowerParams(C.Structure):
+    _fields_ = [("n_feat", C.c_int32), ("emb_dim", C.c_int32), ("n_num", C.c_int32), ("n_layers", C.c_int32),
+                ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("ldw", C.c_int32 * MAX_LAYERS),
+                ("tables", _FP), ("table_off", _FP), ("cards", _FP),
+                ("w", _FP * MAX_LAYERS), ("b", _FP * MAX_LAYERS)]
+
+
+class EncoderLayer(C.Structure):
+    _fields_ = [(n, _FP) for n in ("w_v", "b_v", "w_o", "b_o", "ln1_g", "ln1_b", "w_1", "b_1", "w_2", "b_2",
+                                   "ln2_g", "ln2_b")] + [("ldw_dm", C.c_int32), ("ldw_ff", C.c_int32)]
+
+
+class RankerParams(C.Structure):
+    _fields_ = [("n_user_feat", C.c_int32), ("n_ad_feat", C.c_int32), ("emb_dim", C.c_int32), ("n_num", C.c_int32),
+                ("d_model", C.c_int32), ("d_ff", C.c_int32), ("n_layers", C.c_int32), ("n_cross", C.c_int32),
+                ("n_tasks", C.c_int32), ("head_h1", C.c_int32), ("head_h2", C.c_int32), ("ln_eps", C.c_float),
+                ("ldw_proj", C.c_int32), ("ldw_cross", C.c_int32), ("ldw_head1", C.c_int32),
+                ("ldw_head2", C.c_int32),
+                ("tables", _FP), ("table_off", _FP), ("cards", _FP), ("w_proj", _FP), ("b_proj", _FP),
+                ("layers", EncoderLayer * MAX_LAYERS),
+                ("cross_wt", _FP * MAX_LAYERS), ("cross_b", _FP * MAX_LAYERS),
+                ("head_w1", _FP), ("head_b1", _FP),
+                ("head_w2", _FP * MAX_TASKS), ("head_b2", _FP * MAX_TASKS),
+                ("head_w3", _FP * MAX_TASKS), ("head_b3", _FP * MAX_TASKS)]
+
+
+def _np64(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().double().numpy()
+    return np.asarray(t, dtype=np.float64)
+
+
+def _pad_k(w64, mult=32):
+    out_f, k = w64.shape
+    ld = (k + mult - 1) // mult * mult
+    w = np.zeros((out_f, ld), dtype=np.float32)
+    w[:, :k] = w64.astype(np.float32)
+    return w, ld
+
+
+class Packed:
+    """Keeps the device tensors alive and hands out pointers."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._keep: List[torch.Tensor] = []
+
+    def dev(self, arr, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if dtype is not None:
+            t = t.to(dtype)
+        t = t.to(self.device)
+        assert t.data_ptr() % 16 == 0
+        self._keep.append(t)
+        return t
+
+    def ptr(self, arr, dtype=None):
+        return C.c_void_p(self.dev(arr, dtype).data_ptr())
+
+
+def pack_tables(pk: Packed, tables: List, emb_dim: int):
+    cards = [int(t.shape[0]) for t in tables]
+    off = np.concatenate([[0], np.cumsum(cards)[:-1]]).astype(np.int32)
+    cat = np.concatenate([_np64(t).astype(np.float32) for t in tables], axis=0)
+    assert cat.shape[1] == emb_dim
+    return pk.ptr(cat), pk.ptr(off), pk.ptr(np.asarray(cards, dtype=np.int32)), cards
+
+
+def pack_tower(sd: Dict, prefix: str, feature_names: List[str], n_num: int, device, bn_eps=1e-5):
+    """sd: state_dict-like (torch tensors or numpy) with the reference's key names under
+    ``prefix`` ('user_tower' / 'ad_tower').  -> (TowerParams, Packed)"""
+    pk = Packed(device)
+    tables = [sd[f"{prefix}.embedding_layer.embeddings.{n}.weight"] for n in feature_names]
+    emb_dim = int(tables[0].shape[1])
+    if emb_dim < 4 or emb_dim & (emb_dim - 1):
+        raise ValueError("embedding_dim must be a power of two >= 4 for the fused gather")
+    p = TowerParams()
+    p.n_feat, p.emb_dim, p.n_num = len(tables), emb_dim, n_num
+    p.tables, p.table_off, p.cards, _ = pack_tables(pk, tables, emb_dim)
+    p.dims[0] = len(tables) * emb_dim + n_num
+    idx, l = 0, 0
+    while f"{prefix}.mlp.{idx}.weight" in sd:
+        w = _np64(sd[f"{prefix}.mlp.{idx}.weight"])
+        b = _np64(sd[f"{prefix}.mlp.{idx}.bias"])
+        if f"{prefix}.mlp.{idx + 1}.running_mean" in sd:      # Linear followed by BatchNorm1d (eval)
+            g = _np64(sd[f"{prefix}.mlp.{idx + 1}.weight"])
+            be = _np64(sd[f"{prefix}.mlp.{idx + 1}.bias"])
+            mu = _np64(sd[f"{prefix}.mlp.{idx + 1}.running_mean"])
+            var = _np64(sd[f"{prefix}.mlp.{idx + 1}.running_var"])
+            s = g / np.sqrt(var + bn_eps)
+            w = w * s[:, None]
+            b = (b - mu) * s + be
+            idx += 4
+        else:
+            idx += 1
+        if l >= MAX_LAYERS:
+            raise ValueError("too many layers")
+        if w.shape[0] % 4:
+            raise ValueError("layer widths must be multiples of 4")
+        wp, ld = _pad_k(w)
+        p.w[l], p.b[l], p.ldw[l], p.dims[l + 1] = pk.ptr(wp), pk.ptr(b.astype(np.float32)), ld, w.shape[0]
+        l += 1
+    p.n_layers = l
+    return p, pk
+
+
+def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int, device, ln_eps=1e-5):
+    """state_dict-like of the reference TransformerRanker -> (RankerParams, Packed)."""
+    pk = Packed(device)
+    tables = [sd[f"user_embeddings.{n}.weight"] for n in user_names] + \
+             [sd[f"ad_embeddings.{n}.weight"] for n in ad_names]
+    emb_dim = int(tables[0].shape[1])
+    if emb_dim < 4 or emb_dim & (emb_dim - 1):
+        raise ValueError("embedding_dim must be a power of two >= 4 for the fused gather")
+    p = RankerParams()
+    p.n_user_feat, p.n_ad_feat, p.emb_dim, p.n_num = len(user_names), len(ad_names), emb_dim, n_num
+    p.tables, p.table_off, p.cards, _ = pack_tables(pk, tables, emb_dim)
+    wproj = _np64(sd["feature_projection.weight"])
+    d_model = wproj.shape[0]
+    assert wproj.shape[1] == len(tables) * emb_dim + n_num
+    p.d_model = d_model
+    w, p.ldw_proj = _pad_k(wproj)
+    p.w_proj = pk.ptr(w)
+    pos0 = _np64(sd["positional_encoding"])[0, 0]                  # only row 0 is ever read (:361)
+    p.b_proj = pk.ptr((_np64(sd["feature_projection.bias"]) + pos0).astype(np.float32))
+    l = 0
+    while f"transformer_layers.{l}.norm1.weight" in sd:
+        pre = f"transformer_layers.{l}"
+        L = p.layers[l]
+        for dst, src in (("w_v", "self_attention.W_v"), ("w_o", "self_attention.W_o"), ("w_1", "feed_forward.fc1")):
+            w, ld = _pad_k(_np64(sd[f"{pre}.{src}.weight"]))
+            setattr(L, dst, pk.ptr(w))
+            L.ldw_dm = ld
+        w, L.ldw_ff = _pad_k(_np64(sd[f"{pre}.feed_forward.fc2.weight"]))
+        L.w_2 = pk.ptr(w)
+        p.d_ff = int(sd[f"{pre}.feed_forward.fc1.weight"].shape[0])
+        for dst, src in (("b_v", "self_attention.W_v.bias"), ("b_o", "self_attention.W_o.bias"),
+                         ("b_1", "feed_forward.fc1.bias"), ("b_2", "feed_forward.fc2.bias"),
+                         ("ln1_g", "norm1.weight"), ("ln1_b", "norm1.bias"),
+                         ("ln2_g", "norm2.weight"), ("ln2_b", "norm2.bias")):
+            setattr(L, dst, pk.ptr(_np64(sd[f"{pre}.{src}"]).astype(np.float32)))
+        l += 1
+    p.n_layers = l
+    if l == 0:
+        p.d_ff = 4
+    c = 0
+    while f"feature_interaction.cross_weights.{c}" in sd:
+        w, p.ldw_cross = _pad_k(_np64(sd[f"feature_interaction.cross_weights.{c}"]).T)   # xl @ W == xl (W^T)^T
+        p.cross_wt[c] = pk.ptr(w)
+        p.cross_b[c] = pk.ptr(_np64(sd[f"feature_interaction.cross_biases.{c}"]).astype(np.float32))
+        c += 1
+    p.n_cross = c
+    tasks = [t for t in TASKS if f"prediction_heads.{t}.0.weight" in sd]
+    p.n_tasks = len(tasks)
+    w1 = np.concatenate([_np64(sd[f"prediction_heads.{t}.0.weight"]) for t in tasks], axis=0)
+    b1 = np.concatenate([_np64(sd[f"prediction_heads.{t}.0.bias"]) for t in tasks], axis=0)
+    p.head_h1 = int(sd[f"prediction_heads.{tasks[0]}.0.weight"].shape[0])
+    p.head_h2 = int(sd[f"prediction_heads.{tasks[0]}.3.weight"].shape[0])
+    w, p.ldw_head1 = _pad_k(w1)
+    p.head_w1, p.head_b1 = pk.ptr(w), pk.ptr(b1.astype(np.float32))
+    for i, t in enumerate(tasks):
+        w, p.ldw_head2 = _pad_k(_np64(sd[f"prediction_heads.{t}.3.weight"]))
+        p.head_w2[i] = pk.ptr(w)
+        p.head_b2[i] = pk.ptr(_np64(sd[f"prediction_heads.{t}.3.bias"]).astype(np.float32))
+        p.head_w3[i] = pk.ptr(_np64(sd[f"prediction_heads.{t}.6.weight"]).reshape(-1).astype(np.float32))
+        p.head_b3[i] = pk.ptr(_np64(sd[f"prediction_heads.{t}.6.bias"]).reshape(-1).astype(np.float32))
+    p.ln_eps = ln_eps
+    return p, pk, tasks

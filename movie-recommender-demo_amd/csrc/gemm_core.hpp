@@ -61,34 +61,41 @@ struct DenseRows {
 struct EmbConcatRows {
     const float* tables;        // all feature tables back to back, [sum(card)][E]
     const int* off;             // [F] first row of feature f in `tables`
-    const long long* cat0;      // [rows][F0]
-    const long long* cat1;      // [rows][F - F0] or nullptr
-    const long long* rowmap1;   // optional: cat1 row = rowmap1[row] (candidate id -> ad table row)
-    const float* num;           // [rows][n_num] or nullptr
-    const int* num_rowdiv;      // unused (reserved)
-    long long rows;
+    const int* card;            // [F] cardinalities: indices are clamped into [0, card) so that a bad
+                                //     index can never fault (it is reported by check_index_kernel)
+    const long long* cat0;      // [.][F0]     row = (row_base + r) / cat0_rowdiv
+    const long long* cat1;      // [.][F - F0] row = rowmap1 ? rowmap1[row_base + r] : row_base + r
+    const long long* rowmap1;   // optional candidate id -> ad-feature-table row
+    const float* num;           // [.][n_num] (same row as cat0) or nullptr
+    long long row_base;         // global index of this chunk's first row
+    long long rows;             // rows in this chunk
+    long long rows1;            // rows of cat1 (rowmap1 values are clamped into [0, rows1))
     int F, F0, E, eshift;       // E == 1 << eshift
     int n_num;
-    int cat0_rowdiv;            // cat0/num row = row / cat0_rowdiv (user row broadcast over candidates)
+    int cat0_rowdiv;            // > 1: one user row broadcast over cat0_rowdiv candidate rows
     __device__ __forceinline__ f32x4 load(long long r, int k) const {
         f32x4 z{0.f, 0.f, 0.f, 0.f};
         if (r >= rows) return z;
-        int fe = F << eshift;
+        const long long gr = row_base + r;
+        const int fe = F << eshift;
         if (k < fe) {
-            int f = k >> eshift;
+            const int f = k >> eshift;
             long long idx;
             if (f < F0) {
-                idx = cat0[(r / cat0_rowdiv) * F0 + f];
+                idx = cat0[(gr / cat0_rowdiv) * F0 + f];
             } else {
-                long long r1 = rowmap1 ? rowmap1[r] : r;
+                long long r1 = rowmap1 ? rowmap1[gr] : gr;
+                r1 = r1 < 0 ? 0 : (r1 >= rows1 ? rows1 - 1 : r1);
                 idx = cat1[r1 * (F - F0) + (f - F0)];
             }
+            const long long hi = card[f] - 1;
+            idx = idx < 0 ? 0 : (idx > hi ? hi : idx);
             return *reinterpret_cast<const f32x4*>(tables + (((long long)off[f] + idx) << eshift) +
                                                    (k & ((1 << eshift) - 1)));
         }
-        int j = k - fe;
+        const int j = k - fe;
         if (num == nullptr || j >= n_num) return z;
-        const float* p = num + (r / cat0_rowdiv) * n_num;
+        const float* p = num + (gr / cat0_rowdiv) * n_num;
         z[0] = p[j];
         if (j + 1 < n_num) z[1] = p[j + 1];
         if (j + 2 < n_num) z[2] = p[j + 2];

@@ -1,0 +1,537 @@
+// Tower and ranker forward passes (eval mode) as chains of fp32-MFMA GEMMs with fused
+// epilogues.  Orientation: P = weights [out_features][K] (the "small" operand, re-read from
+// L2 by every block), Q = data rows [rows][K] (streamed once).  In the accumulator a LANE
+// holds one data row and its REGISTERS hold output features, so per-row reductions
+// (LayerNorm, L2 norm) are in-lane + one lane-half exchange + one 2-wave LDS exchange.
+//
+//   tower  (two_tower_model.py:98-121 / :167-184): gather+concat -> [Linear+BN(folded)+ReLU]*n
+//                                                  -> Linear -> L2 normalise
+//   ranker (transformer_ranker.py:332-380): gather+concat -> Linear(+pos[0]) ->
+//          3x { x = LN(x + W_o(W_v x)) ; x = LN(x + W_2 relu(W_1 x)) } -> 3x cross -> 3 heads
+//          (seq_len == 1, :358, makes the attention exactly W_o(W_v x + b_v) + b_o: SURVEY fact 1)
+#include "gemm_core.hpp"
+#include "../../include/amdrec.h"
+
+namespace amdrec {
+
+using ShapeWide = Shape<2, 4, 4, 2>;    // 256 features x 256 rows per block
+using ShapeNarrow = Shape<2, 4, 1, 2>;  //  64 features x 256 rows per block
+
+// out[row][f] = act(acc + bias[f])
+struct EpiLinear {
+    const float* bias;
+    float* out;
+    long long ldo;
+    long long rows;
+    int nout;
+    int relu;
+    template <int TP, int TQ>
+    __device__ void operator()(Acc<TP, TQ>& acc, float*) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const long long row = acc.q(j, lane);
+            if (row >= rows) continue;
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = acc.p(i, 4 * g, lane);
+                    if (f >= nout) continue;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc.v[i][j][4 * g + e] + b[e];
+                        v[e] = relu ? fmaxf(x, 0.f) : x;
+                    }
+                    *reinterpret_cast<f32x4*>(out + row * ldo + f) = v;
+                }
+        }
+    }
+};
+
+// out[row][f] = x0[row][f] * (acc + bias[f]) + xl[row][f]     (FeatureInteractionLayer :201)
+struct EpiCross {
+    const float* bias;
+    const float* x0;
+    const float* xl;
+    float* out;
+    long long ld;
+    long long rows;
+    int nout;
+    template <int TP, int TQ>
+    __device__ void operator()(Acc<TP, TQ>& acc, float*) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const long long row = acc.q(j, lane);
+            if (row >= rows) continue;
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = acc.p(i, 4 * g, lane);
+                    if (f >= nout) continue;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f);
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(x0 + row * ld + f);
+                    const f32x4 al = *reinterpret_cast<const f32x4*>(xl + row * ld + f);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = a0[e] * (acc.v[i][j][4 * g + e] + b[e]) + al[e];
+                    *reinterpret_cast<f32x4*>(out + row * ld + f) = v;
+                }
+        }
+    }
+};
+
+// Row statistics over the nout (<= 256) features of a row.  The block is one P tile wide
+// (ShapeWide: 2 waves x 128 features), so: in-lane sum over the lane's 64 values, exchange
+// with lane^32 (other row-group half of the same tiles), exchange between the 2 feature
+// waves through LDS.  `red` is [2 phases][2 wp][256 rows].
+template <int TP, int TQ>
+__device__ __forceinline__ void row_allreduce(float (&part)[TQ], float* red, int phase, int wp, int wq, int lane) {
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) part[j] += __shfl_xor(part[j], 32, 64);
+    float* r = red + phase * 512;
+    if (lane < 32) {
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) r[wp * 256 + wq * TQ * 32 + j * 32 + lane] = part[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+        int idx = wq * TQ * 32 + j * 32 + (lane & 31);
+        part[j] = r[idx] + r[256 + idx];
+    }
+}
+
+// out = LayerNorm(resid + acc + bias) * gamma + beta   (transformer_ranker.py:149, :153; eps 1e-5)
+struct EpiResidualLN {
+    const float* bias;
+    const float* resid;
+    const float* gamma;
+    const float* beta;
+    float* out;
+    long long ld;
+    long long rows;
+    int nout;
+    float eps;
+    template <int TP, int TQ>
+    __device__ void operator()(Acc<TP, TQ>& acc, float* smem) const {
+        static_assert(TP == 4 && TQ == 2, "LayerNorm epilogue is written for ShapeWide");
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wp = wave / 4, wq = wave % 4;
+        float s[TQ];
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const long long row = acc.q(j, lane);
+            const bool rv = row < rows;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = acc.p(i, 4 * g, lane);
+                    f32x4 b{0.f, 0.f, 0.f, 0.f}, rs{0.f, 0.f, 0.f, 0.f};
+                    const bool fv = f < nout;
+                    if (fv) b = *reinterpret_cast<const f32x4*>(bias + f);
+                    if (fv && rv) rs = *reinterpret_cast<const f32x4*>(resid + row * ld + f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = fv ? acc.v[i][j][4 * g + e] + b[e] + rs[e] : 0.f;
+                        acc.v[i][j][4 * g + e] = x;
+                        a += x;
+                    }
+                }
+            s[j] = a;
+        }
+        row_allreduce<TP, TQ>(s, smem, 0, wp, wq, lane);
+        const float inv_n = 1.0f / (float)nout;
+        float mean[TQ], q2[TQ];
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            mean[j] = s[j] * inv_n;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = acc.p(i, r, lane);
+                    float dlt = (f < nout) ? acc.v[i][j][r] - mean[j] : 0.f;
+                    a += dlt * dlt;
+                }
+            q2[j] = a;
+        }
+        row_allreduce<TP, TQ>(q2, smem, 1, wp, wq, lane);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const long long row = acc.q(j, lane);
+            if (row >= rows) continue;
+            const float rstd = 1.0f / sqrtf(q2[j] * inv_n + eps);
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = acc.p(i, 4 * g, lane);
+                    if (f >= nout) continue;
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + f);
+                    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + f);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (acc.v[i][j][4 * g + e] - mean[j]) * rstd * ga[e] + be[e];
+                    *reinterpret_cast<f32x4*>(out + row * ld + f) = v;
+                }
+        }
+    }
+};
+
+// out = (acc + bias) / max(||acc + bias||_2, eps)      (F.normalize, two_tower_model.py:119)
+struct EpiL2Norm {
+    const float* bias;
+    float* out;
+    long long ldo;
+    long long rows;
+    int nout;
+    float eps;
+    template <int TP, int TQ>
+    __device__ void operator()(Acc<TP, TQ>& acc, float* smem) const {
+        static_assert(TP == 4 && TQ == 2, "L2-norm epilogue is written for ShapeWide");
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wp = wave / 4, wq = wave % 4;
+        float s[TQ];
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = acc.p(i, 4 * g, lane);
+                    const bool fv = f < nout;
+                    f32x4 b{0.f, 0.f, 0.f, 0.f};
+                    if (fv) b = *reinterpret_cast<const f32x4*>(bias + f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = fv ? acc.v[i][j][4 * g + e] + b[e] : 0.f;
+                        acc.v[i][j][4 * g + e] = x;
+                        a += x * x;
+                    }
+                }
+            s[j] = a;
+        }
+        row_allreduce<TP, TQ>(s, smem, 0, wp, wq, lane);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const long long row = acc.q(j, lane);
+            if (row >= rows) continue;
+            const float inv = 1.0f / fmaxf(sqrtf(s[j]), eps);
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = acc.p(i, 4 * g, lane);
+                    if (f >= nout) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc.v[i][j][4 * g + e] * inv;
+                    *reinterpret_cast<f32x4*>(out + row * ldo + f) = v;
+                }
+        }
+    }
+};
+
+// out[row] = dot(h[row][0..n), w) + b   (last Linear(64,1) of a prediction head + squeeze)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* h, long long ldh, int n, const float* w,
+                                                     const float* b, float* out, long long rows) {
+    // 16 lanes per row, float4 each
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    float a = 0.f;
+    if (row < rows) {
+        for (int c = sub * 4; c < n; c += 64) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(h + row * ldh + c);
+            f32x4 y = *reinterpret_cast<const f32x4*>(w + c);
+            a += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (row < rows && sub == 0) out[row] = a + b[0];
+}
+
+// Validate categorical indices (torch raises IndexError; a kernel must not fault): flag = 1
+// if any index is outside [0, card).  The loaders clamp, so nothing reads out of bounds.
+__global__ void check_index_kernel(const long long* cat, long long rows, int F, const int* card, int* flag) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * F) return;
+    long long v = cat[i];
+    if (v < 0 || v >= card[i % F]) *flag = 1;
+}
+
+static inline DenseRows dense(const float* p, long long rows, long long ld, int K) {
+    return DenseRows{p, rows, (int)ld, K, 30, 1ll << 30};
+}
+
+// y = epilogue(x W^T): dispatch on the output width
+template <class LoadQ, class Epi>
+static hipError_t linear(const float* W, int ldw, int nout, const LoadQ& lq, const Epi& epi, long long rows,
+                         hipStream_t st) {
+    DenseRows lp = dense(W, nout, ldw, ldw);
+    if (nout <= 64) return launch_gemm<ShapeNarrow, true>(lp, lq, epi, ldw, nout, rows, st);
+    return launch_gemm<ShapeWide, true>(lp, lq, epi, ldw, nout, rows, st);
+}
+template <class LoadQ, class Epi>
+static hipError_t linear_wide(const float* W, int ldw, int nout, const LoadQ& lq, const Epi& epi, long long rows,
+                              hipStream_t st) {
+    DenseRows lp = dense(W, nout, ldw, ldw);
+    return launch_gemm<ShapeWide, true>(lp, lq, epi, ldw, nout, rows, st);
+}
+
+static inline int ilog2(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+constexpr long long ROW_CHUNK = 32768;   // rows per pass: activations of a chunk stay in the 256 MiB Infinity Cache
+
+}  // namespace amdrec
+
+using namespace amdrec;
+
+// ============================== towers ==============================================
+static int tower_check(const amdrec_tower_params* p) {
+    REQUIRE(p != nullptr, "params is null");
+    REQUIRE(p->n_feat >= 1 && p->n_feat <= 64, "n_feat out of range");
+    REQUIRE(p->emb_dim >= 4 && (p->emb_dim & (p->emb_dim - 1)) == 0, "emb_dim must be a power of two >= 4");
+    REQUIRE(p->n_num >= 0, "n_num < 0");
+    REQUIRE(p->n_layers >= 1 && p->n_layers <= AMDREC_MAX_LAYERS, "n_layers out of range");
+    REQUIRE(p->dims[0] == p->n_feat * p->emb_dim + p->n_num, "dims[0] != n_feat*emb_dim + n_num");
+    for (int l = 0; l < p->n_layers; ++l) {
+        REQUIRE(p->dims[l + 1] >= 4 && p->dims[l + 1] % 4 == 0, "layer width must be a multiple of 4");
+        REQUIRE(p->ldw[l] % 32 == 0 && p->ldw[l] >= p->dims[l], "ldw must be a multiple of 32 and >= K");
+        REQUIRE(p->w[l] && p->b[l], "null weight pointer");
+    }
+    REQUIRE(p->dims[p->n_layers] <= 256, "output_dim > 256 is not supported by the fused L2-norm epilogue");
+    REQUIRE(p->tables && p->table_off && p->cards, "null table pointer");
+    return AMDREC_OK;
+}
+
+static size_t tower_ws_bytes(const amdrec_tower_params* p, long long rows) {
+    long long chunk = rows < ROW_CHUNK ? rows : ROW_CHUNK;
+    int wmax = 4;
+    for (int l = 1; l < p->n_layers; ++l) wmax = p->dims[l] > wmax ? p->dims[l] : wmax;
+    return align_up((size_t)chunk * wmax * 4, 256) * 2;
+}
+
+extern "C" int amdrec_tower_workspace(const amdrec_tower_params* p, int64_t rows, size_t* bytes) {
+    int rc = tower_check(p);
+    if (rc) return rc;
+    REQUIRE(bytes && rows >= 0, "bad arguments");
+    *bytes = tower_ws_bytes(p, rows);
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_tower_forward(const amdrec_tower_params* p, const int64_t* cat, const float* num,
+                                    int64_t rows, float* out, int64_t ld_out, int* bad_index_flag,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = tower_check(p);
+    if (rc) return rc;
+    if (rows <= 0) return AMDREC_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    REQUIRE(cat && out && (num || p->n_num == 0), "null pointer");
+    REQUIRE(ld_out % 4 == 0 && ld_out >= p->dims[p->n_layers], "bad ld_out");
+    size_t need = tower_ws_bytes(p, rows);
+    if (!workspace || workspace_bytes < need)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const long long chunk = rows < ROW_CHUNK ? rows : ROW_CHUNK;
+    int wmax = 4;
+    for (int l = 1; l < p->n_layers; ++l) wmax = p->dims[l] > wmax ? p->dims[l] : wmax;
+    float* bufs[2] = {reinterpret_cast<float*>(workspace),
+                      reinterpret_cast<float*>((char*)workspace + align_up((size_t)chunk * wmax * 4, 256))};
+    if (bad_index_flag) {
+        long long n = rows * p->n_feat;
+        hipLaunchKernelGGL(check_index_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           (const long long*)cat, (long long)rows, p->n_feat, p->cards, bad_index_flag);
+    }
+    for (long long r0 = 0; r0 < rows; r0 += chunk) {
+        const long long m = rows - r0 < chunk ? rows - r0 : chunk;
+        EmbConcatRows g{};
+        g.tables = p->tables; g.off = p->table_off; g.card = p->cards;
+        g.cat0 = (const long long*)cat; g.cat1 = nullptr; g.rowmap1 = nullptr;
+        g.num = num;
+        g.row_base = r0;
+        g.rows = m; g.F = p->n_feat; g.F0 = p->n_feat; g.E = p->emb_dim; g.eshift = ilog2(p->emb_dim);
+        g.n_num = p->n_num; g.cat0_rowdiv = 1;
+        const float* cur = nullptr;
+        int curw = 0;
+        for (int l = 0; l < p->n_layers; ++l) {
+            const bool last = l == p->n_layers - 1;
+            const int nout = p->dims[l + 1];
+            hipError_t e;
+            if (last) {
+                EpiL2Norm epi{p->b[l], out + r0 * ld_out, (long long)ld_out, m, nout, 1e-12f};
+                e = (l == 0) ? linear_wide(p->w[l], p->ldw[l], nout, g, epi, m, st)
+                             : linear_wide(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), epi, m, st);
+            } else {
+                float* dst = bufs[l & 1];
+                EpiLinear epi{p->b[l], dst, (long long)nout, m, nout, 1};
+                e = (l == 0) ? linear(p->w[l], p->ldw[l], nout, g, epi, m, st)
+                             : linear(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), epi, m, st);
+                cur = dst;
+                curw = nout;
+            }
+            HIP_TRY(e);
+        }
+    }
+    return AMDREC_OK;
+}
+
+// ============================== ranker ==============================================
+static int ranker_check(const amdrec_ranker_params* p) {
+    REQUIRE(p != nullptr, "params is null");
+    REQUIRE(p->n_user_feat >= 0 && p->n_ad_feat >= 0 && p->n_user_feat + p->n_ad_feat >= 1 &&
+                p->n_user_feat + p->n_ad_feat <= 128, "feature counts out of range");
+    REQUIRE(p->emb_dim >= 4 && (p->emb_dim & (p->emb_dim - 1)) == 0, "emb_dim must be a power of two >= 4");
+    REQUIRE(p->d_model >= 4 && p->d_model % 4 == 0 && p->d_model <= 256, "d_model must be a multiple of 4, <= 256");
+    REQUIRE(p->d_ff >= 4 && p->d_ff % 4 == 0, "d_ff must be a multiple of 4");
+    REQUIRE(p->n_layers >= 0 && p->n_layers <= AMDREC_MAX_LAYERS, "n_layers out of range");
+    REQUIRE(p->n_cross >= 0 && p->n_cross <= AMDREC_MAX_LAYERS, "n_cross out of range");
+    REQUIRE(p->n_tasks >= 1 && p->n_tasks <= AMDREC_MAX_TASKS, "n_tasks out of range");
+    REQUIRE(p->head_h1 % 4 == 0 && p->head_h2 % 4 == 0 && p->head_h1 >= 4 && p->head_h2 >= 4, "bad head widths");
+    REQUIRE(p->tables && p->table_off && p->cards && p->w_proj && p->b_proj, "null pointer in params");
+    return AMDREC_OK;
+}
+
+struct RankerWs {
+    size_t off_x, off_t, off_x0, off_h, bytes;
+    long long chunk;
+};
+static RankerWs ranker_ws(const amdrec_ranker_params* p, long long rows) {
+    RankerWs w;
+    w.chunk = rows < ROW_CHUNK ? rows : ROW_CHUNK;
+    if (w.chunk < 1) w.chunk = 1;
+    size_t dm = (size_t)w.chunk * p->d_model * 4;
+    long long hw = p->d_ff;
+    long long headw = (long long)p->n_tasks * (p->head_h1 + p->head_h2);
+    if (headw > hw) hw = headw;
+    size_t o = 0;
+    w.off_x = o;  o = align_up(o + dm, 256);
+    w.off_t = o;  o = align_up(o + dm, 256);
+    w.off_x0 = o; o = align_up(o + dm, 256);
+    w.off_h = o;  o = align_up(o + (size_t)w.chunk * hw * 4, 256);
+    w.bytes = o;
+    return w;
+}
+
+extern "C" int amdrec_ranker_workspace(const amdrec_ranker_params* p, int64_t rows, size_t* bytes) {
+    int rc = ranker_check(p);
+    if (rc) return rc;
+    REQUIRE(bytes && rows >= 0, "bad arguments");
+    *bytes = ranker_ws(p, rows).bytes;
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_t* user_cat, const float* numerical,
+                                     int64_t user_rowdiv, const int64_t* ad_cat, const int64_t* ad_rowmap,
+                                     int64_t rows, float* out_logits, int64_t ld_logits, int* bad_index_flag,
+                                     int64_t n_user_rows, int64_t n_ad_rows, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    int rc = ranker_check(p);
+    if (rc) return rc;
+    if (rows <= 0) return AMDREC_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    REQUIRE(user_rowdiv >= 1, "user_rowdiv must be >= 1");
+    REQUIRE((user_cat || p->n_user_feat == 0) && (ad_cat || p->n_ad_feat == 0) && out_logits, "null pointer");
+    REQUIRE(numerical || p->n_num == 0, "numerical is null");
+    REQUIRE(ld_logits >= rows, "ld_logits < rows");
+    REQUIRE(p->n_ad_feat == 0 || n_ad_rows >= 1, "n_ad_rows must be >= 1");
+    REQUIRE(ad_rowmap != nullptr || p->n_ad_feat == 0 || n_ad_rows >= rows, "ad_cat has fewer rows than the batch");
+    REQUIRE(p->n_user_feat == 0 || n_user_rows * user_rowdiv >= rows, "user_cat has too few rows");
+    RankerWs w = ranker_ws(p, rows);
+    if (!workspace || workspace_bytes < w.bytes)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* X = reinterpret_cast<float*>(ws + w.off_x);
+    float* T = reinterpret_cast<float*>(ws + w.off_t);
+    float* X0 = reinterpret_cast<float*>(ws + w.off_x0);
+    float* H = reinterpret_cast<float*>(ws + w.off_h);
+    const int dm = p->d_model, F0 = p->n_user_feat, F = p->n_user_feat + p->n_ad_feat;
+
+    if (bad_index_flag) {
+        if (F0 && n_user_rows > 0) {
+            long long n = n_user_rows * F0;
+            hipLaunchKernelGGL(check_index_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               (const long long*)user_cat, (long long)n_user_rows, F0, p->cards, bad_index_flag);
+        }
+        if (F - F0 && n_ad_rows > 0) {
+            long long n = n_ad_rows * (F - F0);
+            hipLaunchKernelGGL(check_index_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               (const long long*)ad_cat, (long long)n_ad_rows, F - F0, p->cards + F0, bad_index_flag);
+        }
+    }
+
+    for (long long r0 = 0; r0 < rows; r0 += w.chunk) {
+        const long long m = rows - r0 < w.chunk ? rows - r0 : w.chunk;
+        // ---- embed + project (+ pos[0], folded into b_proj on the host) ----
+        EmbConcatRows g{};
+        g.tables = p->tables; g.off = p->table_off; g.card = p->cards;
+        g.cat0 = (const long long*)user_cat; g.cat1 = (const long long*)ad_cat;
+        g.rowmap1 = (const long long*)ad_rowmap;
+        g.num = numerical;
+        g.row_base = r0;
+        g.rows1 = n_ad_rows > 0 ? n_ad_rows : 1;
+        g.rows = m; g.F = F; g.F0 = F0; g.E = p->emb_dim; g.eshift = ilog2(p->emb_dim);
+        g.n_num = p->n_num; g.cat0_rowdiv = (int)user_rowdiv;
+        {
+            EpiLinear epi{p->b_proj, X, (long long)dm, m, dm, 0};
+            HIP_TRY(linear_wide(p->w_proj, p->ldw_proj, dm, g, epi, m, st));
+        }
+        // ---- encoder layers ----
+        for (int l = 0; l < p->n_layers; ++l) {
+            const amdrec_encoder_layer& L = p->layers[l];
+            {   // T = W_v x + b_v
+                EpiLinear epi{L.b_v, T, (long long)dm, m, dm, 0};
+                HIP_TRY(linear_wide(L.w_v, L.ldw_dm, dm, dense(X, m, dm, dm), epi, m, st));
+            }
+            {   // X = LN1(X + W_o T + b_o)
+                EpiResidualLN epi{L.b_o, X, L.ln1_g, L.ln1_b, X, (long long)dm, m, dm, p->ln_eps};
+                HIP_TRY(linear_wide(L.w_o, L.ldw_dm, dm, dense(T, m, dm, dm), epi, m, st));
+            }
+            {   // H = relu(W_1 X + b_1)
+                EpiLinear epi{L.b_1, H, (long long)p->d_ff, m, p->d_ff, 1};
+                HIP_TRY(linear(L.w_1, L.ldw_dm, p->d_ff, dense(X, m, dm, dm), epi, m, st));
+            }
+            {   // X = LN2(X + W_2 H + b_2)
+                EpiResidualLN epi{L.b_2, X, L.ln2_g, L.ln2_b, X, (long long)dm, m, dm, p->ln_eps};
+                HIP_TRY(linear_wide(L.w_2, L.ldw_ff, dm, dense(H, m, p->d_ff, p->d_ff), epi, m, st));
+            }
+        }
+        // ---- cross layers: xl <- x0 * (xl W_i + b_i) + xl ; x0 = X ----
+        const float* xl = X;
+        for (int c = 0; c < p->n_cross; ++c) {
+            float* dst = (c & 1) ? X0 : T;
+            EpiCross epi{p->cross_b[c], X, xl, dst, (long long)dm, m, dm};
+            HIP_TRY(linear_wide(p->cross_wt[c], p->ldw_cross, dm, dense(xl, m, dm, dm), epi, m, st));
+            xl = dst;
+        }
+        // ---- heads ----
+        const int h1 = p->head_h1, h2 = p->head_h2, nt = p->n_tasks;
+        float* H1 = H;                                   // [m][nt*h1]
+        float* H2 = H + (size_t)m * nt * h1;             // [m][nt*h2]
+        {
+            EpiLinear epi{p->head_b1, H1, (long long)nt * h1, m, nt * h1, 1};
+            HIP_TRY(linear(p->head_w1, p->ldw_head1, nt * h1, dense(xl, m, dm, dm), epi, m, st));
+        }
+        for (int t = 0; t < nt; ++t) {
+            EpiLinear epi{p->head_b2[t], H2 + t * h2, (long long)nt * h2, m, h2, 1};
+            HIP_TRY(linear(p->head_w2[t], p->ldw_head2, h2, dense(H1 + t * h1, m, (long long)nt * h1, h1), epi, m, st));
+            hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, st,
+                               H2 + t * h2, (long long)nt * h2, h2, p->head_w3[t], p->head_b3[t],
+                               out_logits + (long long)t * ld_logits + r0, m);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return AMDREC_OK;
+}
