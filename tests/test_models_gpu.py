@@ -77,9 +77,10 @@ def test_ranker_matches_reference_golden(name, cross):
         with torch.no_grad():
             pred = m(_cu(g[f"B{B}_user_cat"]), _cu(g[f"B{B}_ad_cat"]), _cu(g[f"B{B}_user_num"]))
         assert list(pred) == ["ctr", "engagement", "revenue"]
+        scale = cases.logit_scale({t: g[f"B{B}_{t}"] for t in pred})
         for t in pred:
             assert pred[t].shape == (B,) and pred[t].dtype == torch.float32
-            ok, err = cases.logit_close(pred[t].cpu().numpy(), g[f"B{B}_{t}"])
+            ok, err = cases.logit_close(pred[t].cpu().numpy(), g[f"B{B}_{t}"], scale=scale)
             assert ok, (name, cross, B, t, err)
 
 
@@ -91,8 +92,9 @@ def test_ranker_large_batch_vs_oracle(cross):
     ac = synth.ad_features(ad, B, seed=8)
     pred = m(_cu(uc), _cu(ac), _cu(un))
     ref = oracle.ranker.forward(sd, uc, ac, un)
+    scale = cases.logit_scale(ref)
     for t in ref:
-        ok, err = cases.logit_close(pred[t].cpu().numpy(), ref[t])
+        ok, err = cases.logit_close(pred[t].cpu().numpy(), ref[t], scale=scale)
         assert ok, (cross, t, err)
 
 
@@ -105,8 +107,9 @@ def test_ranker_score_candidates_broadcast_and_gather():
     cand = rng.integers(0, N, (U, k))
     pred = m.score_candidates(_cu(uc), _cu(un), _cu(cand), _cu(table), check_indices=True)
     ref = oracle.ranker.forward(sd, np.repeat(uc, k, axis=0), table[cand.reshape(-1)], np.repeat(un, k, axis=0))
+    scale = cases.logit_scale(ref)
     for t in ref:
-        ok, err = cases.logit_close(pred[t].cpu().numpy(), ref[t])
+        ok, err = cases.logit_close(pred[t].cpu().numpy(), ref[t], scale=scale)
         assert ok, (t, err)
 
 

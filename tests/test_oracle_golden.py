@@ -35,8 +35,9 @@ def test_ranker_oracle_matches_reference(name, cross):
     for B in batches:
         pred = oracle.ranker.forward(sd, g[f"B{B}_user_cat"], g[f"B{B}_ad_cat"], g[f"B{B}_user_num"])
         assert list(pred) == ["ctr", "engagement", "revenue"]
+        scale = cases.logit_scale({t: g[f"B{B}_{t}"] for t in pred})
         for t in pred:
-            ok, err = cases.logit_close(pred[t], g[f"B{B}_{t}"])
+            ok, err = cases.logit_close(pred[t], g[f"B{B}_{t}"], scale=scale)
             assert ok, (name, cross, B, t, err)
 
 
