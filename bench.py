@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""End-to-end recommendations/s on the BASELINE.json workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric / configs[2]): synthetic corpus of 1 000 000 ads,
+d = 256 (randn rows L2-normalised, seed 1234, the reference benchmark's distribution
+faiss_retrieval.py:390), per-ad categorical table ad_cat[1M,20], seeded random-init two-tower
+and ranker weights with the reference's architecture; one STEP = one batch of 512 users per GPU
+through the whole hot path with inputs resident in HBM:
+    UserTower -> L2 renorm -> exact inner-product top-500 -> TransformerRanker on the 500
+    candidates of every user -> top-10 by CTR logit (+ sigmoid of the 3 tasks).
+N > 1: the corpus is row-sharded over the ranks (1M/N rows each), every rank searches its shard
+for the global batch (512*N users), the per-shard top-500 lists are exchanged with one RCCL
+all-gather, each rank merges and ranks its own 512 users ("scaling": "weak").
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "movie-recommender-demo_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+N_ADS = 1_000_000
+DIM = 256
+USERS_PER_GPU = 512
+STAGE1_K = 500
+TOP_K = 10
+FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def _t(sd):
+    return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+
+
+def build_models(device, seed=7):
+    from amdrec import synth
+    from amdrec.ranker import TransformerRanker
+    from amdrec.towers import TwoTowerModel
+    user, ad, nnum = synth.demo_dims()
+    tt_sd = synth.two_tower_state(user, ad, nnum, seed=seed)
+    rk_sd = synth.ranker_state(user, ad, nnum, seed=seed + 1, cross_scale=1.0 / 16)
+    tt = TwoTowerModel(dict(user), dict(ad), nnum)
+    tt.load_state_dict(_t(tt_sd))
+    rk = TransformerRanker(dict(user), dict(ad), nnum)
+    rk.load_state_dict(_t(rk_sd))
+    return tt.to(device).eval(), rk.to(device).eval(), (tt_sd, rk_sd), (user, ad, nnum)
+
+
+def device_corpus(n, dim, device, seed=1234, row0=0, rows=None):
+    """randn rows, L2-normalised, generated on the device in fixed 65536-row blocks so that any
+    shard [row0, row0+rows) of the same (n, seed) corpus is bit-identical on every rank."""
+    rows = n - row0 if rows is None else rows
+    out = torch.empty((rows, dim), dtype=torch.float32, device=device)
+    blk = 65536
+    b0, b1 = row0 // blk, (row0 + rows + blk - 1) // blk
+    for b in range(b0, b1):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1_000_003 + b)
+        x = torch.randn((blk, dim), generator=g, device=device, dtype=torch.float32)
+        x = x / x.norm(dim=1, keepdim=True).clamp_min(1e-30)
+        s, e = max(b * blk, row0), min((b + 1) * blk, row0 + rows, n)
+        if e > s:
+            out[s - row0:e - row0] = x[s - b * blk:e - b * blk]
+    return out
+
+
+def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, n_users):
+    """The CPU oracle (port of the reference path) timed on this host's cores on a bounded
+    sample of the same workload: n_users users against the full 1M corpus."""
+    import oracle
+    from amdrec import synth
+    user, ad, nnum = dims
+    idx = oracle.search.FlatIndex(DIM)
+    idx.add(corpus_cpu)                                   # index build is not timed (nor is it on the GPU)
+    uc, un = synth.user_batch(user, nnum, n_users, seed=4242)
+    t0 = time.time()
+    oracle.pipeline.recommend(tt_sd, rk_sd, idx, ad_table_cpu, uc, un, TOP_K, STAGE1_K)
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {"value": n_users / dt, "unit": "recs/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n_users} users x 1M ads end-to-end through oracle/ (numpy fp32), {dt:.1f}s; "
+                      "faiss unavailable - numpy restatement"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-users", type=int, default=48)
+    ap.add_argument("--sweep", action="store_true", help="also print the search-only B sweep (stderr)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from amdrec import _lib, synth
+    from amdrec.index import FAISSIndex
+    from amdrec.pipeline import AdRecommenderInference
+    _lib.load()
+
+    tt, rk, (tt_sd, rk_sd), dims = build_models(device)
+    user, ad, nnum = dims
+    per = (N_ADS + world - 1) // world
+    row0, rows = rank * per, max(0, min(per, N_ADS - rank * per))
+    shard = device_corpus(N_ADS, DIM, device, row0=row0, rows=rows)
+    index = FAISSIndex(DIM, index_type="Flat", device=device)
+    index.add(shard)                                        # renormalises + stores (faiss_retrieval.py:97-127)
+    del shard
+    ad_table = torch.from_numpy(synth.ad_features(ad, N_ADS, seed=99)).to(device)   # replicated (160 MB)
+    rec = AdRecommenderInference(two_tower_model=tt, transformer_ranker=rk, faiss_index=index,
+                                 ad_features=ad_table)
+    B_global = USERS_PER_GPU * world
+    uc_np, un_np = synth.user_batch(user, nnum, B_global, seed=2024)
+    uc, un = torch.from_numpy(uc_np).to(device), torch.from_numpy(un_np).to(device)
+
+    if world > 1:
+        from amdrec.sharded import ShardedRecommender
+        runner = ShardedRecommender(rec, rank, world, shard_offset=row0)
+        step = lambda: runner.recommend_device(uc, un, TOP_K, STAGE1_K)     # noqa: E731
+    else:
+        step = lambda: rec.recommend_device(uc, un, TOP_K, STAGE1_K)        # noqa: E731
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _lib.profile_enable(True)                # HIP events around every GEMM launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_report()
+    _lib.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert out["ad_ids"].shape[-1] == TOP_K
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1000
+        value = B_global * args.steps / dt
+        # dominant kernel = the GEMM tag with the largest total time in the timed region
+        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"]) if prof else None
+        roofline = None
+        if dom:
+            name, p = dom
+            avg_ms = p["total_ms"] / p["launches"]
+            achieved = p["flops"] / p["launches"] / (avg_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                        "kernel": name, "launches_per_step": p["launches"] / args.steps,
+                        "avg_launch_ms": round(avg_ms, 4),
+                        "alg_gflop_per_launch": round(p["flops"] / p["launches"] / 1e9, 3)}
+        kernels = {k: {"ms_per_step": round(v["total_ms"] / args.steps, 3),
+                       "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None,
+                       "launches_per_step": v["launches"] / args.steps} for k, v in sorted(prof.items())}
+        sf = prof.get("search_filter_256x256")
+        search = None
+        if sf:
+            ms = sf["total_ms"] / sf["launches"]
+            alg_bytes = rows * DIM * 4 + B_global * DIM * 4 + B_global * STAGE1_K * 12
+            search = {"filter_pass_ms": round(ms, 3), "alg_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+                      "hbm_frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "tflops": round(sf["flops"] / sf["launches"] / (ms * 1e-3) / 1e12, 2),
+                      "note": "B=512 per corpus pass is fp32-FLOP bound (intensity 255 FLOP/B vs ridge 19.7)"}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            corpus_cpu = index._xb[:index._n].cpu().numpy()
+            cpu = cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table.cpu().numpy(), args.cpu_users)
+        line = {"metric": "end-to-end recs/sec (1M ads d=256, top-500->10)", "value": round(value, 1),
+                "unit": "recs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[2]: 1M synthetic ads d=256, UserTower batch=512/GPU, "
+                                       "exact IP top-500, TransformerRanker(256,8 heads,3 layers) on 500 cands, top-10",
+                           "n_ads": N_ADS, "dim": DIM, "users_per_step": B_global, "stage1_k": STAGE1_K,
+                           "top_k": TOP_K, "corpus_rows_per_gpu": rows,
+                           "parallelism": f"corpus row-sharded x{world}, ranker data-parallel over users"},
+                "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "search": search}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,27 @@ int amdrec_l2_normalize(const float* in, int64_t ld_in, float* out, int64_t ld_o
 int amdrec_remap_ids(const int64_t* pos, const int64_t* id_map, int64_t n_map, int64_t* out,
                      int64_t n, void* stream);
 
+/* Optional per-launch timing: HIP events recorded on the launch stream around every GEMM-shaped
+ * kernel launch, accumulated per kernel tag ("<epilogue>_<BP>x<BQ>", DESIGN.md maps tags to
+ * symbol names).  flops / bytes are the ALGORITHMIC 2*M*N*K and operand+result bytes of the
+ * launches.  amdrec_profile_report synchronises with the recorded events. */
+typedef struct {
+    char name[64];
+    int64_t launches;
+    double total_ms, flops, bytes;
+} amdrec_profile_entry;
+int amdrec_profile_enable(int on);   /* also clears the counters */
+int amdrec_profile_report(amdrec_profile_entry* out /*host*/, int max_entries, int* n /*host*/);
+
+/* Stage-2 selection (inference.py:258-263: sigmoid -> np.argsort(ctr)[::-1][:top_k]): per user
+ * the top_k of its k_c candidates by the LOGIT of task `rank_task` (sigmoid is monotone), order
+ * (logit desc, candidate slot asc).  out_ids[u][i] = cand_ids[u][slot], out_scores[t][u][i] =
+ * sigmoid(logits[t][u*k_c + slot]), out_slots (optional) = the winning slots. */
+int amdrec_select_topk(const float* logits /*[n_tasks][ld]*/, int64_t ld_logits, int n_tasks,
+                       int rank_task, const int64_t* cand_ids /*[n_users][k_c]*/, int64_t n_users,
+                       int k_c, int top_k, int64_t* out_ids /*[n_users][top_k]*/,
+                       float* out_scores /*[n_tasks][n_users][top_k]*/, int32_t* out_slots, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,9 @@ _SIGNATURES = {
     "amdrec_ranker_forward": [_vp, _vp, _fp, _i64, _vp, _vp, _i64, _fp, _i64, _vp, _i64, _i64, _vp, _sz, _vp],
     "amdrec_l2_normalize": [_fp, _i64, _fp, _i64, _i64, _i32, _vp],
     "amdrec_remap_ids": [_vp, _vp, _i64, _vp, _i64, _vp],
+    "amdrec_profile_enable": [_i32],
+    "amdrec_profile_report": [_vp, _i32, C.POINTER(_i32)],
+    "amdrec_select_topk": [_fp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _fp, _vp, _vp],
 }
 _RESTYPE = {"amdrec_last_error": C.c_char_p}
 
@@ -86,6 +89,24 @@ def require_gpu(t, name, dtype=None):
     if dtype is not None and t.dtype != dtype:
         raise AmdrecError(f"{name} must be {dtype}, got {t.dtype}")
     return t
+
+
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+def profile_enable(on: bool):
+    check(load().amdrec_profile_enable(1 if on else 0))
+
+
+def profile_report():
+    """-> {tag: dict(launches, total_ms, flops, bytes)} (synchronises with the recorded events)."""
+    arr = (ProfileEntry * 64)()
+    n = C.c_int(0)
+    check(load().amdrec_profile_report(C.cast(arr, C.c_void_p), 64, C.byref(n)))
+    return {arr[i].name.decode(): {"launches": arr[i].launches, "total_ms": arr[i].total_ms,
+                                   "flops": arr[i].flops, "bytes": arr[i].bytes} for i in range(n.value)}
 
 
 class Workspace:

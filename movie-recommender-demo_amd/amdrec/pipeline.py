@@ -1,0 +1,236 @@
+"""Drop-in for the reference's serving pipeline ``AdRecommenderInference`` (inference.py:21-331).
+
+``recommend_ads(user_data, top_k=10, stage1_k=500, return_scores=True)`` keeps the reference's
+argument names / defaults, stage order, ranking key (CTR only, inference.py:263) and result
+schema (:272-288).  The whole hot path stays on the device between the feature tensors and
+the final ``[B, top_k]`` result: UserTower -> L2 renorm -> exact IP top-``stage1_k`` ->
+ranker over the candidates (user row broadcast, ad features gathered from a resident table)
+-> top-``top_k``.  The reference crosses the host/device boundary four times per request
+(inference.py:225-229, :241-248, :258-260); this path crosses it once each way.
+
+Deviations, each forced by a reference defect:
+* candidate ad features come from a real ``ad_features[N, 20]`` table indexed by corpus position
+  (the reference draws ``torch.randint`` placeholders, inference.py:246-248);
+* unknown categories map to ``'rare'`` if the encoder has it, else class 0 (the reference asks
+  the encoder for a ``'missing'`` class that does not exist, inference.py:180);
+* numerical features are cast to float32 after scaling (the reference feeds float64 into a
+  float32 model, inference.py:193-195);
+* the preprocessor sidecar is JSON (``preprocessor.json``), never a pickle.
+"""
+from __future__ import annotations
+
+import json
+import time
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .index import FAISSIndex
+from .ranker import TransformerRanker
+from .towers import TwoTowerModel
+
+USER_COLS = [f"C{i}" for i in range(1, 7)]      # inference.py:46
+AD_COLS = [f"C{i}" for i in range(7, 27)]       # inference.py:47
+TASKS = ("ctr", "engagement", "revenue")
+
+
+class Preprocessor:
+    """The fitted state of CriteoDataPreprocessor that inference needs (data_preprocessing.py:
+    label encoders' classes, numerical column list, StandardScaler mean/scale), as plain data."""
+
+    def __init__(self, classes: Dict[str, List[str]], numerical_cols: List[str], mean, scale):
+        self.classes = {c: list(v) for c, v in classes.items()}
+        self._lookup = {c: {s: i for i, s in enumerate(v)} for c, v in self.classes.items()}
+        self.numerical_cols = list(numerical_cols)
+        self.mean = np.asarray(mean, dtype=np.float64)
+        self.scale = np.asarray(scale, dtype=np.float64)
+        self.feature_dims = {c: len(v) for c, v in self.classes.items()}
+
+    def encode(self, col, value) -> int:
+        lut = self._lookup[col]
+        if value in lut:
+            return lut[value]
+        return lut.get("rare", 0)
+
+    def save(self, path):
+        with open(path, "w") as f:
+            json.dump({"classes": self.classes, "numerical_cols": self.numerical_cols,
+                       "mean": self.mean.tolist(), "scale": self.scale.tolist()}, f)
+
+    @classmethod
+    def load(cls, path):
+        with open(path) as f:
+            d = json.load(f)
+        return cls(d["classes"], d["numerical_cols"], d["mean"], d["scale"])
+
+
+def _load_checkpoint(model, path, device):
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    sd = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt  # :101-106
+    model.load_state_dict(sd)
+    return model.to(device).eval()
+
+
+class AdRecommenderInference:
+    def __init__(self, model_dir: Optional[str] = None, device: str = "cuda", *,
+                 two_tower_model: Optional[TwoTowerModel] = None,
+                 transformer_ranker: Optional[TransformerRanker] = None,
+                 faiss_index: Optional[FAISSIndex] = None, ad_features=None,
+                 preprocessor: Optional[Preprocessor] = None, verbose: bool = False):
+        """Either ``model_dir`` (files below) or the components directly.
+        model_dir: preprocessor.json, two_tower_{best,final}.pt, transformer_ranker_{best,final}.pt,
+        faiss_index.bin (+ .metadata) in this build's format, ad_features.npy [N, 20]."""
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.AmdrecError("AdRecommenderInference needs a HIP device (no CPU fallback)")
+        self.verbose = verbose
+        _lib.load()
+        if model_dir is not None:
+            d = Path(model_dir)
+            self.preprocessor = Preprocessor.load(d / "preprocessor.json")
+            self.user_feature_dims = {c: self.preprocessor.feature_dims[c] for c in USER_COLS
+                                      if c in self.preprocessor.feature_dims}
+            self.ad_feature_dims = {c: self.preprocessor.feature_dims[c] for c in AD_COLS
+                                    if c in self.preprocessor.feature_dims}
+            self.numerical_dim = len(self.preprocessor.numerical_cols)
+            tt = TwoTowerModel(self.user_feature_dims, self.ad_feature_dims, self.numerical_dim)   # :84-92
+            p = d / "two_tower_best.pt"
+            self.two_tower_model = _load_checkpoint(tt, p if p.exists() else d / "two_tower_final.pt", self.device)
+            rk = TransformerRanker(self.user_feature_dims, self.ad_feature_dims, self.numerical_dim)  # :114-124
+            p = d / "transformer_ranker_best.pt"
+            self.transformer_ranker = _load_checkpoint(
+                rk, p if p.exists() else d / "transformer_ranker_final.pt", self.device)
+            self.faiss_index = FAISSIndex(256, index_type="IVF", nlist=100, nprobe=10, device=self.device)  # :145-151
+            self.faiss_index.load(str(d / "faiss_index.bin"))
+            ad_features = np.load(d / "ad_features.npy", allow_pickle=False)
+        else:
+            if two_tower_model is None or transformer_ranker is None or faiss_index is None or ad_features is None:
+                raise ValueError("pass model_dir or all of two_tower_model, transformer_ranker, faiss_index, "
+                                 "ad_features")
+            self.preprocessor = preprocessor
+            self.two_tower_model = two_tower_model.to(self.device).eval()
+            self.transformer_ranker = transformer_ranker.to(self.device).eval()
+            self.faiss_index = faiss_index
+        if isinstance(ad_features, torch.Tensor):
+            self.ad_features = ad_features.to(device=self.device, dtype=torch.int64).contiguous()
+        else:
+            self.ad_features = torch.from_numpy(np.ascontiguousarray(ad_features, dtype=np.int64)).to(self.device)
+        if self.ad_features.shape[0] < self.faiss_index.index.ntotal:
+            raise ValueError("ad_features has fewer rows than the index")
+
+    # -- host-side feature prep (inference.py:160-197; CPU string work, not the hot path) -----
+    def preprocess_user_features(self, user_data: dict):
+        if self.preprocessor is None:
+            raise ValueError("no preprocessor loaded")
+        pp = self.preprocessor
+        cat = [pp.encode(c, user_data["categorical"].get(c, "missing")) for c in USER_COLS if c in pp.classes]
+        num = np.array([np.log1p(np.abs(user_data["numerical"].get(c, 0))) for c in pp.numerical_cols],
+                       dtype=np.float64)
+        num = ((num - pp.mean) / pp.scale).astype(np.float32)
+        return torch.tensor([cat], dtype=torch.long), torch.from_numpy(num[None, :])
+
+    # -- the device hot path ------------------------------------------------------------------
+    def _stage1(self, uc, un, stage1_k, check_indices):
+        emb = self.two_tower_model.user_tower.encode(uc, un, check_indices=check_indices)      # :223-227
+        return self.faiss_index.search_device(emb, stage1_k, normalize=True,                   # :230-232
+                                              return_positions=True)
+
+    def _stage2(self, uc, un, cand_pos, top_k, check_indices):
+        lib = _lib.load()
+        B, stage1_k = cand_pos.shape
+        tasks, logits = self.transformer_ranker.score_candidates(uc, un, cand_pos, self.ad_features,  # :241-255
+                                                                 check_indices=check_indices, raw=True)
+        ad_ids = torch.empty((B, top_k), dtype=torch.int64, device=uc.device)
+        scores = torch.empty((len(tasks), B, top_k), dtype=torch.float32, device=uc.device)
+        idx = self.faiss_index
+        if idx._identity:
+            cand_ids = torch.where(cand_pos < 0, cand_pos + idx._n, cand_pos) if idx._n else cand_pos
+        else:
+            cand_ids = torch.empty_like(cand_pos)
+            _lib.check(lib.amdrec_remap_ids(_lib.ptr(cand_pos), _lib.ptr(idx._ids), idx._n, _lib.ptr(cand_ids),
+                                            cand_pos.numel(), _lib.stream_ptr(uc.device)))
+        if B:
+            _lib.check(lib.amdrec_select_topk(_lib.ptr(logits), logits.stride(0), len(tasks), tasks.index("ctr"),
+                                              _lib.ptr(cand_ids), B, stage1_k, top_k, _lib.ptr(ad_ids),
+                                              _lib.ptr(scores), None, _lib.stream_ptr(uc.device)))
+        return {"ad_ids": ad_ids, "scores": scores, "tasks": tasks, "candidate_ids": cand_ids, "logits": logits}
+
+    @torch.no_grad()
+    def recommend_device(self, user_categorical: torch.Tensor, user_numerical: torch.Tensor, top_k: int = 10,
+                         stage1_k: int = 500, check_indices: bool = False):
+        """[B,6] / [B,13] device tensors -> dict of device tensors, no host synchronisation:
+        ad_ids [B,top_k] int64, scores [3,B,top_k] float32 (sigmoid of the logits), candidate_ids
+        [B,stage1_k], candidate_scores [B,stage1_k], logits [3, B*stage1_k]."""
+        uc = _lib.require_gpu(user_categorical, "user_categorical")
+        un = _lib.require_gpu(user_numerical, "user_numerical")
+        cand_pos, cand_scores = self._stage1(uc, un, stage1_k, check_indices)
+        out = self._stage2(uc, un, cand_pos, top_k, check_indices)
+        out["candidate_scores"] = cand_scores
+        return out
+
+    # -- reference API ------------------------------------------------------------------------
+    def recommend_ads(self, user_data: dict, top_k: int = 10, stage1_k: int = 500,
+                      return_scores: bool = True) -> dict:
+        """inference.py:199-288."""
+        return self.batch_recommend([user_data], top_k=top_k, stage1_k=stage1_k,
+                                    return_scores=return_scores)[0]
+
+    def batch_recommend(self, user_data_list: list, top_k: int = 10, stage1_k: int = 500,
+                        return_scores: bool = True) -> list:
+        """inference.py:290-331 - but one device pass for the whole list instead of a serial loop.
+        ``timing`` reports the batch's stage times divided by the number of users."""
+        if not user_data_list:
+            return []
+        feats = [self.preprocess_user_features(u) for u in user_data_list]
+        uc = torch.cat([f[0] for f in feats])
+        un = torch.cat([f[1] for f in feats])
+        return self.recommend_tensors(uc, un, top_k, stage1_k, return_scores)
+
+    @torch.no_grad()
+    def recommend_tensors(self, user_categorical, user_numerical, top_k=10, stage1_k=500, return_scores=True):
+        """Tensor-level entry (cf. TwoStageRetriever.retrieve_and_rank, faiss_retrieval.py:283-369);
+        result dicts follow inference.py:272-288."""
+        t0 = time.time()
+        uc = user_categorical.to(self.device)
+        un = user_numerical.to(self.device)
+        n = uc.shape[0]
+        cand_pos, _ = self._stage1(uc, un, stage1_k, True)
+        torch.cuda.synchronize(self.device)
+        t1 = time.time()
+        out = self._stage2(uc, un, cand_pos, top_k, True)
+        ids = out["ad_ids"].cpu().numpy()
+        sc = out["scores"].cpu().numpy()
+        t2 = time.time()
+        stage1_ms, stage2_ms = (t1 - t0) * 1000 / max(n, 1), (t2 - t1) * 1000 / max(n, 1)
+        res = []
+        for b in range(n):
+            r = {"ad_ids": ids[b].tolist(),
+                 "timing": {"stage1_ms": stage1_ms, "stage2_ms": stage2_ms, "total_ms": stage1_ms + stage2_ms}}
+            if return_scores:
+                r["scores"] = {t: sc[i, b].tolist() for i, t in enumerate(out["tasks"])}
+            res.append(r)
+        return res
+
+
+def build_faiss_index(model: TwoTowerModel, ad_categorical, device="cuda", save_path: Optional[str] = None,
+                      batch_size: int = 1 << 18, index_type: str = "IVF", nlist: int = 100,
+                      nprobe: int = 10) -> FAISSIndex:
+    """Corpus build (training_pipeline.py:488-546): AdTower over every row in dataset order
+    (shuffle=False, :513), ad id = row index (:523), add to the index, optionally save.
+    ``ad_categorical`` is the [N, 20] integer table; embeddings never leave the device."""
+    model = model.to(device).eval()
+    table = ad_categorical if isinstance(ad_categorical, torch.Tensor) else torch.from_numpy(
+        np.ascontiguousarray(ad_categorical))
+    idx = FAISSIndex(model.output_dim, index_type=index_type, nlist=nlist, nprobe=nprobe, device=device)
+    embs = []
+    with torch.no_grad():
+        for s in range(0, table.shape[0], batch_size):
+            embs.append(model.get_ad_embeddings(table[s:s + batch_size].to(device)))
+    emb = torch.cat(embs) if embs else torch.empty((0, model.output_dim), device=device)
+    idx.add(emb)                                         # default ids = arange (:523 / faiss_retrieval.py:121)
+    if save_path:
+        idx.save(save_path)
+    return idx

@@ -96,7 +96,7 @@ class TransformerRanker(nn.Module):
         return r
 
     # -- forward ----------------------------------------------------------------------
-    def _run(self, user_cat, numerical, user_rowdiv, ad_cat, ad_rowmap, rows, check_indices=True):
+    def _run(self, user_cat, numerical, user_rowdiv, ad_cat, ad_rowmap, rows, check_indices=True, raw=False):
         if self.training:
             raise NotImplementedError("the HIP forward implements eval() semantics only; call .eval()")
         dev = ad_cat.device
@@ -104,7 +104,7 @@ class TransformerRanker(nn.Module):
         lib = _lib.load()
         logits = torch.empty((len(tasks), rows), dtype=torch.float32, device=dev)
         if rows == 0:
-            return {t: logits[i] for i, t in enumerate(tasks)}
+            return (tasks, logits) if raw else {t: logits[i] for i, t in enumerate(tasks)}
         flag = torch.zeros(1, dtype=torch.int32, device=dev) if check_indices else None
         nbytes = _lib.C.c_size_t(0)
         _lib.check(lib.amdrec_ranker_workspace(_lib.C.byref(params), rows, _lib.C.byref(nbytes)))
@@ -115,7 +115,7 @@ class TransformerRanker(nn.Module):
             user_cat.shape[0], ad_cat.shape[0], _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
         if check_indices and int(flag.item()):
             raise IndexError("index out of range in self")
-        return {t: logits[i] for i, t in enumerate(tasks)}
+        return (tasks, logits) if raw else {t: logits[i] for i, t in enumerate(tasks)}
 
     def forward(self, user_categorical, ad_categorical, numerical, mask: Optional[torch.Tensor] = None):
         """transformer_ranker.py:332-380 -> {'ctr','engagement','revenue'}: logits [B]."""
@@ -128,10 +128,12 @@ class TransformerRanker(nn.Module):
             raise ValueError("bad feature shapes")
         return self._run(uc, nm, 1, ac, None, B)
 
-    def score_candidates(self, user_categorical, numerical, candidate_rows, ad_table, check_indices=False):
+    def score_candidates(self, user_categorical, numerical, candidate_rows, ad_table, check_indices=False,
+                         raw=False):
         """Pipeline form of inference.py:241-255: user u's features are broadcast over its
         ``k = candidate_rows.shape[1]`` candidates (no .repeat), ad features are gathered from the
-        resident ``ad_table [N, n_ad_feat]`` by candidate row.  -> logits dict, each [U*k]."""
+        resident ``ad_table [N, n_ad_feat]`` by candidate row.  -> logits dict, each [U*k]
+        (``raw=True``: (task names, one [n_tasks, U*k] tensor))."""
         uc = _lib.require_gpu(user_categorical, "user_categorical").long().contiguous()
         nm = _lib.require_gpu(numerical, "numerical").to(torch.float32).contiguous()
         cand = _lib.require_gpu(candidate_rows, "candidate_rows", torch.int64).contiguous()
@@ -141,7 +143,7 @@ class TransformerRanker(nn.Module):
         U, k = cand.shape
         if uc.shape[0] != U or nm.shape[0] != U:
             raise ValueError("one user row per candidate list expected")
-        return self._run(uc, nm, k, table, cand.view(-1), U * k, check_indices)
+        return self._run(uc, nm, k, table, cand.view(-1), U * k, check_indices, raw)
 
     def compute_loss(self, *a, **k):
         raise NotImplementedError("training (transformer_ranker.py:382-415) is outside the MI355X hot path")

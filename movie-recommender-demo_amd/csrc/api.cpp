@@ -16,5 +16,76 @@ int set_error(int code, const char* fmt, ...) {
 }
 }  // namespace amdrec
 
+// ---- profiling ------------------------------------------------------------------------
+#include <mutex>
+#include <string>
+#include <vector>
+namespace amdrec {
+bool g_prof_on = false;
+namespace {
+struct Rec { int tag; hipEvent_t a, b; };
+struct Tag { std::string name; long long launches; double ms, flops, bytes; };
+std::vector<Rec> g_recs;
+std::vector<Tag> g_tags;
+std::vector<hipEvent_t> g_pool;
+std::mutex g_mu;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : slot(-1), st(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int t = -1;
+    for (size_t i = 0; i < g_tags.size(); ++i) if (g_tags[i].name == tag) { t = (int)i; break; }
+    if (t < 0) { g_tags.push_back(Tag{tag, 0, 0, 0, 0}); t = (int)g_tags.size() - 1; }
+    g_tags[t].launches++; g_tags[t].flops += flops; g_tags[t].bytes += bytes;
+    Rec r{t, get_event(), get_event()};
+    (void)hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+    slot = (int)g_recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipEventRecord(g_recs[slot].b, st);
+}
+}  // namespace amdrec
+
+extern "C" int amdrec_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(amdrec::g_mu);
+    for (auto& r : amdrec::g_recs) { amdrec::g_pool.push_back(r.a); amdrec::g_pool.push_back(r.b); }
+    amdrec::g_recs.clear();
+    amdrec::g_tags.clear();
+    amdrec::g_prof_on = on != 0;
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_profile_report(amdrec_profile_entry* out, int max_entries, int* n) {
+    REQUIRE(n != nullptr && (out != nullptr || max_entries == 0), "null pointer");
+    std::lock_guard<std::mutex> lk(amdrec::g_mu);
+    for (auto& r : amdrec::g_recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        amdrec::g_tags[r.tag].ms += ms;
+        amdrec::g_pool.push_back(r.a);
+        amdrec::g_pool.push_back(r.b);
+    }
+    amdrec::g_recs.clear();
+    int cnt = 0;
+    for (auto& t : amdrec::g_tags) {
+        if (cnt >= max_entries) break;
+        amdrec_profile_entry& e = out[cnt++];
+        snprintf(e.name, sizeof(e.name), "%s", t.name.c_str());
+        e.launches = t.launches; e.total_ms = t.ms; e.flops = t.flops; e.bytes = t.bytes;
+    }
+    *n = cnt;
+    return AMDREC_OK;
+}
+
 extern "C" int amdrec_abi_version(void) { return AMDREC_ABI_VERSION; }
 extern "C" const char* amdrec_last_error(void) { return amdrec::g_err; }

@@ -67,4 +67,14 @@ __host__ __device__ inline uint32_t key_pos(unsigned long long k) { return ~(uin
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- optional per-launch timing (amdrec_profile_*): HIP events recorded on the launch stream
+// around each GEMM launch, accumulated per kernel tag.  Off by default (zero cost).
+struct ProfScope {
+    int slot;
+    hipStream_t st;
+    ProfScope(const char* tag, double flops, double bytes, hipStream_t st);
+    ~ProfScope();
+};
+extern bool g_prof_on;
+
 }  // namespace amdrec

@@ -236,9 +236,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
     epi(acc, smem);
 }
 
+// k_alg: the un-padded K (for the algorithmic FLOP/byte count of the profiling hook only)
 template <class S, bool P_IS_SMALL, class LoadP, class LoadQ, class Epi>
 inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, int K, long long p_rows,
-                              long long q_rows, hipStream_t stream) {
+                              long long q_rows, hipStream_t stream, int k_alg = 0) {
     auto kern = gemm_nt_kernel<S, P_IS_SMALL, LoadP, LoadQ, Epi>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -253,6 +254,12 @@ inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, 
     tm.tiles_big = P_IS_SMALL ? tiles_q : tiles_p;
     if (tm.tiles_small <= 0 || tm.tiles_big <= 0) return hipSuccess;
     int ksteps = (K + BK - 1) / BK;
+    char tag[64];
+    if (g_prof_on) snprintf(tag, sizeof(tag), "%s_%dx%d", Epi::name, S::BP, S::BQ);
+    const double ka = k_alg > 0 ? k_alg : K;
+    ProfScope prof(tag, 2.0 * (double)p_rows * (double)q_rows * ka,
+                   4.0 * ((double)p_rows * ka + (double)q_rows * ka + Epi::out_bytes_per_elem * (double)p_rows * (double)q_rows),
+                   stream);
     hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(NTHREADS), S::LDS_BYTES, stream, lp, lq, epi, ksteps, tm);
     return hipGetLastError();
 }

@@ -19,6 +19,8 @@ using ShapeNarrow = Shape<2, 4, 1, 2>;  //  64 features x 256 rows per block
 
 // out[row][f] = act(acc + bias[f])
 struct EpiLinear {
+    static constexpr const char* name = "linear";
+    static constexpr double out_bytes_per_elem = 1.0;
     const float* bias;
     float* out;
     long long ldo;
@@ -53,6 +55,8 @@ struct EpiLinear {
 
 // out[row][f] = x0[row][f] * (acc + bias[f]) + xl[row][f]     (FeatureInteractionLayer :201)
 struct EpiCross {
+    static constexpr const char* name = "cross";
+    static constexpr double out_bytes_per_elem = 1.0;
     const float* bias;
     const float* x0;
     const float* xl;
@@ -108,6 +112,8 @@ __device__ __forceinline__ void row_allreduce(float (&part)[TQ], float* red, int
 
 // out = LayerNorm(resid + acc + bias) * gamma + beta   (transformer_ranker.py:149, :153; eps 1e-5)
 struct EpiResidualLN {
+    static constexpr const char* name = "residual_ln";
+    static constexpr double out_bytes_per_elem = 1.0;
     const float* bias;
     const float* resid;
     const float* gamma;
@@ -188,6 +194,8 @@ struct EpiResidualLN {
 
 // out = (acc + bias) / max(||acc + bias||_2, eps)      (F.normalize, two_tower_model.py:119)
 struct EpiL2Norm {
+    static constexpr const char* name = "l2norm";
+    static constexpr double out_bytes_per_elem = 1.0;
     const float* bias;
     float* out;
     long long ldo;
@@ -276,16 +284,16 @@ static inline DenseRows dense(const float* p, long long rows, long long ld, int 
 // y = epilogue(x W^T): dispatch on the output width
 template <class LoadQ, class Epi>
 static hipError_t linear(const float* W, int ldw, int nout, const LoadQ& lq, const Epi& epi, long long rows,
-                         hipStream_t st) {
+                         hipStream_t st, int k_alg) {
     DenseRows lp = dense(W, nout, ldw, ldw);
-    if (nout <= 64) return launch_gemm<ShapeNarrow, true>(lp, lq, epi, ldw, nout, rows, st);
-    return launch_gemm<ShapeWide, true>(lp, lq, epi, ldw, nout, rows, st);
+    if (nout <= 64) return launch_gemm<ShapeNarrow, true>(lp, lq, epi, ldw, nout, rows, st, k_alg);
+    return launch_gemm<ShapeWide, true>(lp, lq, epi, ldw, nout, rows, st, k_alg);
 }
 template <class LoadQ, class Epi>
 static hipError_t linear_wide(const float* W, int ldw, int nout, const LoadQ& lq, const Epi& epi, long long rows,
-                              hipStream_t st) {
+                              hipStream_t st, int k_alg) {
     DenseRows lp = dense(W, nout, ldw, ldw);
-    return launch_gemm<ShapeWide, true>(lp, lq, epi, ldw, nout, rows, st);
+    return launch_gemm<ShapeWide, true>(lp, lq, epi, ldw, nout, rows, st, k_alg);
 }
 
 static inline int ilog2(int v) {
@@ -372,13 +380,13 @@ extern "C" int amdrec_tower_forward(const amdrec_tower_params* p, const int64_t*
             hipError_t e;
             if (last) {
                 EpiL2Norm epi{p->b[l], out + r0 * ld_out, (long long)ld_out, m, nout, 1e-12f};
-                e = (l == 0) ? linear_wide(p->w[l], p->ldw[l], nout, g, epi, m, st)
-                             : linear_wide(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), epi, m, st);
+                e = (l == 0) ? linear_wide(p->w[l], p->ldw[l], nout, g, epi, m, st, p->dims[l])
+                             : linear_wide(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), epi, m, st, p->dims[l]);
             } else {
                 float* dst = bufs[l & 1];
                 EpiLinear epi{p->b[l], dst, (long long)nout, m, nout, 1};
-                e = (l == 0) ? linear(p->w[l], p->ldw[l], nout, g, epi, m, st)
-                             : linear(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), epi, m, st);
+                e = (l == 0) ? linear(p->w[l], p->ldw[l], nout, g, epi, m, st, p->dims[l])
+                             : linear(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), epi, m, st, p->dims[l]);
                 cur = dst;
                 curw = nout;
             }
@@ -486,26 +494,26 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         g.n_num = p->n_num; g.cat0_rowdiv = (int)user_rowdiv;
         {
             EpiLinear epi{p->b_proj, X, (long long)dm, m, dm, 0};
-            HIP_TRY(linear_wide(p->w_proj, p->ldw_proj, dm, g, epi, m, st));
+            HIP_TRY(linear_wide(p->w_proj, p->ldw_proj, dm, g, epi, m, st, F * p->emb_dim + p->n_num));
         }
         // ---- encoder layers ----
         for (int l = 0; l < p->n_layers; ++l) {
             const amdrec_encoder_layer& L = p->layers[l];
             {   // T = W_v x + b_v
                 EpiLinear epi{L.b_v, T, (long long)dm, m, dm, 0};
-                HIP_TRY(linear_wide(L.w_v, L.ldw_dm, dm, dense(X, m, dm, dm), epi, m, st));
+                HIP_TRY(linear_wide(L.w_v, L.ldw_dm, dm, dense(X, m, dm, dm), epi, m, st, dm));
             }
             {   // X = LN1(X + W_o T + b_o)
                 EpiResidualLN epi{L.b_o, X, L.ln1_g, L.ln1_b, X, (long long)dm, m, dm, p->ln_eps};
-                HIP_TRY(linear_wide(L.w_o, L.ldw_dm, dm, dense(T, m, dm, dm), epi, m, st));
+                HIP_TRY(linear_wide(L.w_o, L.ldw_dm, dm, dense(T, m, dm, dm), epi, m, st, dm));
             }
             {   // H = relu(W_1 X + b_1)
                 EpiLinear epi{L.b_1, H, (long long)p->d_ff, m, p->d_ff, 1};
-                HIP_TRY(linear(L.w_1, L.ldw_dm, p->d_ff, dense(X, m, dm, dm), epi, m, st));
+                HIP_TRY(linear(L.w_1, L.ldw_dm, p->d_ff, dense(X, m, dm, dm), epi, m, st, dm));
             }
             {   // X = LN2(X + W_2 H + b_2)
                 EpiResidualLN epi{L.b_2, X, L.ln2_g, L.ln2_b, X, (long long)dm, m, dm, p->ln_eps};
-                HIP_TRY(linear_wide(L.w_2, L.ldw_ff, dm, dense(H, m, p->d_ff, p->d_ff), epi, m, st));
+                HIP_TRY(linear_wide(L.w_2, L.ldw_ff, dm, dense(H, m, p->d_ff, p->d_ff), epi, m, st, p->d_ff));
             }
         }
         // ---- cross layers: xl <- x0 * (xl W_i + b_i) + xl ; x0 = X ----
@@ -513,7 +521,7 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         for (int c = 0; c < p->n_cross; ++c) {
             float* dst = (c & 1) ? X0 : T;
             EpiCross epi{p->cross_b[c], X, xl, dst, (long long)dm, m, dm};
-            HIP_TRY(linear_wide(p->cross_wt[c], p->ldw_cross, dm, dense(xl, m, dm, dm), epi, m, st));
+            HIP_TRY(linear_wide(p->cross_wt[c], p->ldw_cross, dm, dense(xl, m, dm, dm), epi, m, st, dm));
             xl = dst;
         }
         // ---- heads ----
@@ -522,11 +530,11 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         float* H2 = H + (size_t)m * nt * h1;             // [m][nt*h2]
         {
             EpiLinear epi{p->head_b1, H1, (long long)nt * h1, m, nt * h1, 1};
-            HIP_TRY(linear(p->head_w1, p->ldw_head1, nt * h1, dense(xl, m, dm, dm), epi, m, st));
+            HIP_TRY(linear(p->head_w1, p->ldw_head1, nt * h1, dense(xl, m, dm, dm), epi, m, st, dm));
         }
         for (int t = 0; t < nt; ++t) {
             EpiLinear epi{p->head_b2[t], H2 + t * h2, (long long)nt * h2, m, h2, 1};
-            HIP_TRY(linear(p->head_w2[t], p->ldw_head2, h2, dense(H1 + t * h1, m, (long long)nt * h1, h1), epi, m, st));
+            HIP_TRY(linear(p->head_w2[t], p->ldw_head2, h2, dense(H1 + t * h1, m, (long long)nt * h1, h1), epi, m, st, h1));
             hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, st,
                                H2 + t * h2, (long long)nt * h2, h2, p->head_w3[t], p->head_b3[t],
                                out_logits + (long long)t * ld_logits + r0, m);

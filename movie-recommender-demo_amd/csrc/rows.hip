@@ -39,9 +39,76 @@ __global__ void remap_ids_kernel(const long long* pos, const long long* id_map, 
     out[i] = (p >= 0 && p < n_map) ? id_map[p] : -1;
 }
 
+// Stage-2 selection (inference.py:258-263, faiss_retrieval.py:355-358): per user, the top_k of
+// its k_c candidates by the ranking task's LOGIT (sigmoid is monotone; ranking on logits avoids
+// the ties of saturated sigmoids), order (logit desc, candidate slot asc); then sigmoid of every
+// task's logit at the winners and the winners' ad ids.  One block per user, bitonic sort of
+// 64-bit (logit, ~slot) keys in LDS.
+__global__ __launch_bounds__(256) void select_topk_kernel(const float* logits, long long ld, int n_tasks,
+                                                          int rank_task, const long long* cand_ids, int k_c,
+                                                          int top_k, long long* out_ids, float* out_scores,
+                                                          int* out_slots, long long n_users) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const long long u = blockIdx.x;
+    int P = 2;
+    while (P < k_c) P <<= 1;
+    const float* lr = logits + (long long)rank_task * ld + u * k_c;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        unsigned long long key = 0ull;
+        if (i < k_c) {
+            float v = lr[i];
+            if (v == v) key = make_key(v, (uint32_t)i);     // NaN logits rank last
+            else key = (unsigned long long)(~(uint32_t)i) | (1ull << 32);
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int sz = 2; sz <= P; sz <<= 1)
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = threadIdx.x; i < P; i += blockDim.x) {
+                int j = i ^ st;
+                if (j > i) {
+                    unsigned long long a = keys[i], b = keys[j];
+                    bool desc = (i & sz) == 0;
+                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < top_k; i += blockDim.x) {
+        const bool valid = i < k_c;
+        const int slot = valid ? (int)key_pos(keys[i]) : -1;
+        out_ids[u * top_k + i] = valid ? cand_ids[u * k_c + slot] : -1;
+        if (out_slots) out_slots[u * top_k + i] = slot;
+        for (int t = 0; t < n_tasks; ++t) {
+            float x = valid ? logits[(long long)t * ld + u * k_c + slot] : -INFINITY;
+            out_scores[((long long)t * n_users + u) * top_k + i] = 1.0f / (1.0f + expf(-x));
+        }
+    }
+}
+
 }  // namespace amdrec
 
 using namespace amdrec;
+
+extern "C" int amdrec_select_topk(const float* logits, int64_t ld_logits, int n_tasks, int rank_task,
+                                  const int64_t* cand_ids, int64_t n_users, int k_c, int top_k, int64_t* out_ids,
+                                  float* out_scores, int32_t* out_slots, void* stream) {
+    REQUIRE(n_tasks >= 1 && rank_task >= 0 && rank_task < n_tasks, "bad task index");
+    REQUIRE(k_c >= 1 && k_c <= AMDREC_MAX_K, "candidates per user must be in [1,%d]", AMDREC_MAX_K);
+    REQUIRE(top_k >= 1 && top_k <= AMDREC_MAX_K, "top_k out of range");
+    if (n_users <= 0) return AMDREC_OK;
+    REQUIRE(logits && cand_ids && out_ids && out_scores, "null pointer");
+    REQUIRE(ld_logits >= n_users * k_c, "ld_logits too small");
+    int P = 2;
+    while (P < k_c) P <<= 1;
+    hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)n_users), dim3(256), (size_t)P * 8,
+                       reinterpret_cast<hipStream_t>(stream), logits, (long long)ld_logits, n_tasks, rank_task,
+                       (const long long*)cand_ids, k_c, top_k, (long long*)out_ids, out_scores, out_slots,
+                       (long long)n_users);
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
 
 extern "C" int amdrec_l2_normalize(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t rows,
                                    int dim, void* stream) {
