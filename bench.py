@@ -92,6 +92,10 @@ def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, n_users):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         threads = os.cpu_count()
+    try:
+        threads = min(threads, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
     return {"value": n_users / dt, "unit": "recs/s", "cores": int(threads), "kind": "port",
             "sample": f"{n_users} users x 1M ads end-to-end through oracle/ (numpy fp32), {dt:.1f}s; "
                       "faiss unavailable - numpy restatement"}
@@ -209,9 +213,40 @@ def main():
                            "parallelism": f"corpus row-sharded x{world}, ranker data-parallel over users"},
                 "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "search": search}
         print(json.dumps(line), flush=True)
+    if args.sweep and rank == 0 and world == 1:
+        search_sweep(index, device)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def search_sweep(index, device, reps=20):
+    """Search-only sweep over queries per corpus pass: achieved algorithmic HBM GB/s
+    and fp32 TFLOP/s of the whole search call (sample + threshold + filter + finalize)."""
+    n = index._n
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    q = torch.randn((512, DIM), generator=g, device=device)
+    q = q / q.norm(dim=1, keepdim=True)
+    rows = []
+    for B in (1, 8, 32, 128, 512):
+        qq = q[:B].contiguous()
+        for _ in range(3):
+            index.search_device(qq, STAGE1_K, normalize=False)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            index.search_device(qq, STAGE1_K, normalize=False)
+        e1.record()
+        torch.cuda.synchronize(device)
+        ms = e0.elapsed_time(e1) / reps
+        alg_bytes = n * DIM * 4 + B * DIM * 4 + B * STAGE1_K * 12
+        flops = 2.0 * B * n * DIM
+        rows.append({"B": B, "ms": round(ms, 4), "qps": round(B / ms * 1e3, 1),
+                     "alg_GBps": round(alg_bytes / ms / 1e6, 1), "hbm_frac": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                     "tflops": round(flops / ms / 1e9, 2), "fp32_frac": round(flops / ms / 1e9 / FP32_PEAK_TFLOPS, 4)})
+    print(json.dumps({"search_sweep_1M_k500": rows}), file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":

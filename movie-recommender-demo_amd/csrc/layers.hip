@@ -302,7 +302,11 @@ static inline int ilog2(int v) {
     return s;
 }
 
-constexpr long long ROW_CHUNK = 32768;   // rows per pass: activations of a chunk stay in the 256 MiB Infinity Cache
+// Rows per pass.  A 256-feature layer launches rows/256 workgroups, so a pass must be >= 65536 rows to
+// give every one of the 256 CUs a block and several times that to keep the last wave of blocks full
+// (measured: 32768-row passes left half the chip idle, 45-74 TF; fp32 GEMMs are MFMA-bound, not
+// HBM-bound, so keeping a pass inside the Infinity Cache buys nothing here).
+constexpr long long ROW_CHUNK = 262144;
 
 }  // namespace amdrec
 
