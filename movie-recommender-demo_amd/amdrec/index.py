@@ -182,9 +182,10 @@ class FAISSIndex:
         return self._ids[:self._n].tolist()
 
     def search_device(self, queries: torch.Tensor, k: int, normalize: bool = True,
-                      return_positions: bool = False):
+                      return_positions: bool = False, pos_offset: int = 0):
         """Device-to-device search, asynchronous on the current stream.
-        -> (ids int64 [nq,k], scores float32 [nq,k]) on the device."""
+        -> (ids int64 [nq,k], scores float32 [nq,k]) on the device.  ``return_positions``: corpus
+        positions (+ ``pos_offset``, the shard's first global row) instead of ids, -1 = unfilled."""
         q = _lib.require_gpu(queries, "queries")
         q = q.to(dtype=torch.float32, copy=True) if normalize else q
         if q.dim() != 2 or q.shape[1] != self.dimension:
@@ -198,7 +199,7 @@ class FAISSIndex:
         if self.index_type == "IVF":
             self._ivf.search(self._xb, self._n, q, k, self.nprobe, scores, pos)
         else:
-            flat_search(self._xb, self._n, q, k, scores, pos)
+            flat_search(self._xb, self._n, q, k, scores, pos, pos_offset=pos_offset if return_positions else 0)
         if return_positions or self._identity:
             # identity map: id == position for filled slots; unfilled (-1) slots map to
             # id_map[-1] in the reference (:159) - reproduce that too

@@ -138,7 +138,7 @@ class AdRecommenderInference:
         return self.faiss_index.search_device(emb, stage1_k, normalize=True,                   # :230-232
                                               return_positions=True)
 
-    def _stage2(self, uc, un, cand_pos, top_k, check_indices):
+    def _stage2(self, uc, un, cand_pos, top_k, check_indices, ids_are_positions=False):
         lib = _lib.load()
         B, stage1_k = cand_pos.shape
         tasks, logits = self.transformer_ranker.score_candidates(uc, un, cand_pos, self.ad_features,  # :241-255
@@ -146,7 +146,9 @@ class AdRecommenderInference:
         ad_ids = torch.empty((B, top_k), dtype=torch.int64, device=uc.device)
         scores = torch.empty((len(tasks), B, top_k), dtype=torch.float32, device=uc.device)
         idx = self.faiss_index
-        if idx._identity:
+        if ids_are_positions:
+            cand_ids = cand_pos
+        elif idx._identity:
             cand_ids = torch.where(cand_pos < 0, cand_pos + idx._n, cand_pos) if idx._n else cand_pos
         else:
             cand_ids = torch.empty_like(cand_pos)

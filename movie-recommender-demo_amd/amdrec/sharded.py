@@ -1,0 +1,112 @@
+"""Corpus-sharded serving across the GPUs of one node (absent in the reference,
+which is single-process / device 0 only, faiss_retrieval.py:76-78).
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI).  Rank r holds corpus
+rows [offset_r, offset_r + n_r); weights and the ad-feature table are replicated.  One step:
+
+  1. every rank encodes the GLOBAL user batch (the tower is 0.26 GFLOP per 512 users - cheaper
+     than broadcasting embeddings) and searches ITS shard for all users -> [B_g, k] scores and
+     global positions;
+  2. ONE all-gather of a packed per-rank buffer [scores f32 | positions i64] (12 B per
+     candidate; 3.07 MB per rank at 512 x 500) - one fused collective instead of two; the
+     payload is latency-bound on xGMI, so no ring-sized bucketing is needed;
+  3. rank r merges the world's lists for ITS contiguous slice of users (G*k -> k, exact, same
+     order rule as the single-GPU search: the result is bit-identical to an unsharded search);
+  4. rank r ranks its own users' candidates (data parallel) and selects their top-k.
+
+The compute steps go through an ``engine`` so that the orchestration (slicing, packing, the
+collective, offsets) can be exercised on CPU under gloo with a test engine; the default
+engine is the HIP one and refuses CPU tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def user_slice(n_users: int, rank: int, world: int):
+    """Contiguous block of users owned by ``rank`` (ceil division, last ranks may be short/empty)."""
+    per = (n_users + world - 1) // world
+    q0 = min(rank * per, n_users)
+    return q0, min(per, n_users - q0)
+
+
+def packed_layout(n_users: int, k: int):
+    """Byte layout of one rank's all-gather chunk: [scores f32 [B,k] | pad | positions i64 [B,k]]."""
+    s_bytes = (n_users * k * 4 + 7) // 8 * 8
+    return s_bytes, s_bytes + n_users * k * 8
+
+
+class HipEngine:
+    """The product engine: libamdrec kernels behind an AdRecommenderInference."""
+
+    def __init__(self, rec, shard_offset: int):
+        self.rec = rec
+        self.shard_offset = int(shard_offset)
+
+    def local_search(self, uc, un, k):
+        emb = self.rec.two_tower_model.user_tower.encode(uc, un, check_indices=False)
+        pos, scores = self.rec.faiss_index.search_device(emb, k, normalize=True, return_positions=True,
+                                                         pos_offset=self.shard_offset)
+        return scores, pos
+
+    def merge(self, gathered: torch.Tensor, world: int, n_users: int, k: int, q0: int, nq: int):
+        lib = _lib.load()
+        s_bytes, chunk = packed_layout(n_users, k)
+        dev = gathered.device
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        out_p = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        base = gathered.data_ptr()
+        _lib.check(lib.amdrec_topk_merge(_lib.C.c_void_p(base), _lib.C.c_void_p(base + s_bytes), world, chunk,
+                                         q0, nq, k, _lib.ptr(out_s), _lib.ptr(out_p), _lib.stream_ptr(dev)))
+        return out_s, out_p
+
+    def rank(self, uc, un, cand_pos, top_k):
+        return self.rec._stage2(uc, un, cand_pos, top_k, False, ids_are_positions=True)
+
+
+class ShardedRecommender:
+    def __init__(self, rec, rank: int, world: int, shard_offset: int, group: Optional[dist.ProcessGroup] = None,
+                 engine=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.engine = engine if engine is not None else HipEngine(rec, shard_offset)
+
+    @torch.no_grad()
+    def recommend_device(self, user_categorical, user_numerical, top_k: int = 10, stage1_k: int = 500):
+        """Global user batch (identical on every rank) -> this rank's users' results:
+        dict(ad_ids [nq,top_k], scores [3,nq,top_k], user_offset q0, candidate_ids, candidate_scores)."""
+        uc, un = user_categorical, user_numerical
+        B, k = uc.shape[0], stage1_k
+        scores, pos = self.engine.local_search(uc, un, k)                     # [B,k] each
+        s_bytes, chunk = packed_layout(B, k)
+        buf = torch.empty(chunk, dtype=torch.uint8, device=scores.device)
+        buf[:B * k * 4].view(torch.float32).copy_(scores.reshape(-1))
+        buf[s_bytes:].view(torch.int64).copy_(pos.reshape(-1))
+        gathered = torch.empty(chunk * self.world, dtype=torch.uint8, device=scores.device)
+        dist.all_gather_into_tensor(gathered, buf, group=self.group)          # ONE collective per step
+        q0, nq = user_slice(B, self.rank, self.world)
+        cand_scores, cand_pos = self.engine.merge(gathered, self.world, B, k, q0, nq)
+        out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
+        out["candidate_scores"] = cand_scores
+        out["user_offset"] = q0
+        return out
+
+    @torch.no_grad()
+    def recommend_all(self, user_categorical, user_numerical, top_k: int = 10, stage1_k: int = 500):
+        """Same, then all-gather the final [nq, top_k] results so every rank holds all users
+        (~60 KB at 512 x 10).  Requires n_users % world == 0."""
+        out = self.recommend_device(user_categorical, user_numerical, top_k, stage1_k)
+        B = user_categorical.shape[0]
+        if B % self.world:
+            raise ValueError("recommend_all needs n_users divisible by the world size")
+        ids = torch.empty((B, top_k), dtype=torch.int64, device=out["ad_ids"].device)
+        dist.all_gather_into_tensor(ids, out["ad_ids"].contiguous(), group=self.group)
+        sc = out["scores"]                                                    # [T, nq, top_k]
+        T = sc.shape[0]
+        sc_all = torch.empty((self.world, T, B // self.world, top_k), dtype=sc.dtype, device=sc.device)
+        dist.all_gather_into_tensor(sc_all, sc.contiguous(), group=self.group)
+        return {"ad_ids": ids, "scores": sc_all.permute(1, 0, 2, 3).reshape(T, B, top_k), "tasks": out["tasks"]}

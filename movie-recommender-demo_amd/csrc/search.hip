@@ -292,6 +292,33 @@ __global__ __launch_bounds__(512) void fixup_merge_kernel(const unsigned long lo
     write_result(keys, total < k ? total : k, k, q, outD, outI, pos_offset);
 }
 
+// Cross-shard merge: n_lists sorted top-k lists per query (one per corpus shard,
+// positions already global) -> the global top-k.  One block per query, bitonic sort in LDS.
+__global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, const char* pos, int n_lists,
+                                                         long long list_stride_bytes, long long q0, int k,
+                                                         float* outD, long long* outI) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const long long q = blockIdx.x;
+    const int total = n_lists * k;
+    int P = 2;
+    while (P < total) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        unsigned long long key = 0ull;
+        if (i < total) {
+            const int g = i / k, j = i - g * k;
+            const float* sg = reinterpret_cast<const float*>(scores + (long long)g * list_stride_bytes);
+            const long long* pg = reinterpret_cast<const long long*>(pos + (long long)g * list_stride_bytes);
+            const long long p = pg[(q0 + q) * k + j];
+            const float sc = sg[(q0 + q) * k + j];
+            if (p >= 0 && sc == sc) key = make_key(sc, (uint32_t)p);
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_desc(keys, P);
+    write_result(keys, total < k ? total : k, k, q, outD, outI, 0);
+}
+
 __global__ void fill_f32_kernel(float* p, long long n, float v) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -363,6 +390,28 @@ static hipError_t run_passes(const float* X, long long ldx, long long nrows, int
 }  // namespace amdrec
 
 using namespace amdrec;
+
+extern "C" int amdrec_topk_merge(const float* scores, const int64_t* pos, int n_lists, int64_t list_stride_bytes,
+                                 int64_t q0, int64_t nq, int k, float* out_scores, int64_t* out_pos,
+                                 void* stream) {
+    REQUIRE(n_lists >= 1 && k >= 1 && (long long)n_lists * k <= 16384, "n_lists*k must be in [1,16384]");
+    REQUIRE(list_stride_bytes % 8 == 0 && q0 >= 0, "bad stride/offset");
+    if (nq <= 0) return AMDREC_OK;
+    REQUIRE(scores && pos && out_scores && out_pos, "null pointer");
+    int P = 2;
+    while (P < n_lists * k) P <<= 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(512), (size_t)P * 8,
+                       reinterpret_cast<hipStream_t>(stream), (const char*)scores, (const char*)pos, n_lists,
+                       (long long)list_stride_bytes, (long long)q0, k, out_scores, (long long*)out_pos);
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
 
 extern "C" int amdrec_flat_search_workspace(int64_t nq, int64_t nrows, int k, size_t* bytes) {
     REQUIRE(bytes != nullptr, "bytes is null");

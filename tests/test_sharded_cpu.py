@@ -1,0 +1,135 @@
+"""world_size-2 gloo test of the sharded serving orchestration (amdrec.sharded) on CPU.
+
+The compute engine is injected: here it is the CPU oracle (test infrastructure), so what is
+under test is the product's slicing / packing / all-gather / offset logic - the code path the
+8-GPU RCCL run takes - not the kernels (those are covered by the -m gpu tests)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from amdrec import synth
+from amdrec.sharded import ShardedRecommender, packed_layout, user_slice
+from tests import cases
+
+N_ADS, B, K1, TOPK = 3001, 7, 50, 5
+
+
+class OracleEngine:
+    def __init__(self, tt_sd, rk_sd, corpus, offset, ad_table):
+        self.tt_sd, self.rk_sd, self.offset, self.ad_table = tt_sd, rk_sd, offset, ad_table
+        self.index = oracle.search.FlatIndex(corpus.shape[1])
+        self.index.add(corpus)
+
+    def local_search(self, uc, un, k):
+        emb = oracle.towers.user_tower(self.tt_sd, uc.numpy(), un.numpy())
+        q = oracle.search.normalize_l2(emb)
+        D, I = oracle.search.flat_ip_search(self.index.xb, q, k)
+        I = np.where(I >= 0, I + self.offset, -1)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def merge(self, gathered, world, n_users, k, q0, nq):
+        s_bytes, chunk = packed_layout(n_users, k)
+        raw = gathered.numpy()
+        Ds, Is = [], []
+        for g in range(world):
+            c = raw[g * chunk:(g + 1) * chunk]
+            Ds.append(c[:n_users * k * 4].view(np.float32).reshape(n_users, k)[q0:q0 + nq])
+            Is.append(c[s_bytes:].view(np.int64).reshape(n_users, k)[q0:q0 + nq])
+        D, I = oracle.search.merge_shards(Ds, Is, [0] * world, k)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def rank(self, uc, un, cand_pos, top_k):
+        ids_out, sc_out = [], []
+        for b in range(uc.shape[0]):
+            ids = cand_pos[b].numpy()
+            lg = oracle.ranker.forward(self.rk_sd, np.repeat(uc[b:b + 1].numpy(), len(ids), 0), self.ad_table[ids],
+                                       np.repeat(un[b:b + 1].numpy(), len(ids), 0))
+            top = oracle.pipeline.select_top(lg["ctr"], top_k)
+            ids_out.append(ids[top])
+            sc_out.append(np.stack([oracle.pipeline.sigmoid(lg[t][top]) for t in oracle.ranker.TASKS]))
+        return {"ad_ids": torch.from_numpy(np.stack(ids_out)) if ids_out else torch.zeros((0, top_k), dtype=torch.int64),
+                "scores": torch.from_numpy(np.stack(sc_out, axis=1)) if sc_out else torch.zeros((3, 0, top_k)),
+                "tasks": list(oracle.ranker.TASKS), "candidate_ids": cand_pos}
+
+
+def _inputs():
+    user, ad, nnum = cases.small_dims()
+    tt_sd = synth.two_tower_state(user, ad, nnum, seed=41)
+    rk_sd = synth.ranker_state(user, ad, nnum, seed=42, cross_scale=1.0 / 16)
+    ad_table = synth.ad_features(ad, N_ADS, seed=43)
+    corpus = oracle.towers.ad_tower(tt_sd, ad_table)
+    uc, un = synth.user_batch(user, nnum, B, seed=44)
+    return tt_sd, rk_sd, ad_table, corpus, uc, un
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs()
+        per = (N_ADS + world - 1) // world
+        lo, hi = rank * per, min(N_ADS, (rank + 1) * per)
+        eng = OracleEngine(tt_sd, rk_sd, corpus[lo:hi], lo, ad_table)
+        sr = ShardedRecommender(None, rank, world, lo, engine=eng)
+        out = sr.recommend_device(torch.from_numpy(uc), torch.from_numpy(un), TOPK, K1)
+        q.put((rank, out["user_offset"], out["ad_ids"].numpy(), out["scores"].numpy(),
+               out["candidate_ids"].numpy(), out["candidate_scores"].numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_pipeline_equals_unsharded_oracle():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs()
+    oidx = oracle.search.FlatIndex(256)
+    oidx.add(corpus)
+    ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
+    covered = []
+    for rank, q0, ids, sc, cand, cs in res:
+        assert (q0, len(ids)) == user_slice(B, rank, world)
+        for j in range(len(ids)):
+            r = ref[q0 + j]
+            # sharding must not change anything: merge of exact shard top-k == exact global top-k
+            assert np.array_equal(cand[j], r["candidate_ids"])
+            assert np.array_equal(cs[j], r["candidate_scores"])
+            assert ids[j].tolist() == r["ad_ids"]
+            for ti, t in enumerate(oracle.ranker.TASKS):
+                assert np.allclose(sc[ti, j], r["scores"][t], atol=1e-6)
+            covered.append(q0 + j)
+    assert covered == list(range(B))
+
+
+def test_user_slice_and_layout():
+    assert [user_slice(7, r, 2) for r in range(2)] == [(0, 4), (4, 3)]
+    assert [user_slice(3, r, 4) for r in range(4)] == [(0, 1), (1, 1), (2, 1), (3, 0)]
+    assert [user_slice(4096, r, 8) for r in range(8)] == [(512 * r, 512) for r in range(8)]
+    s, c = packed_layout(7, 5)
+    assert s % 8 == 0 and s >= 7 * 5 * 4 and c == s + 7 * 5 * 8
