@@ -116,11 +116,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    # Rehearsal switch (not used by the driver): AMDREC_BENCH_REHEARSE=1 runs all ranks on cuda:0 over
+    # gloo, so the N>1 code path can be exercised on a one-GPU box.  The numbers it prints are meaningless.
+    rehearse = os.environ.get("AMDREC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from amdrec import _lib, synth
     from amdrec.index import FAISSIndex
@@ -166,7 +174,7 @@ def main():
     prof = _lib.profile_report()
     _lib.profile_enable(False)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert out["ad_ids"].shape[-1] == TOP_K

@@ -69,6 +69,17 @@ class HipEngine:
         return self.rec._stage2(uc, un, cand_pos, top_k, False, ids_are_positions=True)
 
 
+def all_gather_bytes(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """all_gather_into_tensor; device tensors under a gloo group (rehearsal of the multi-rank
+    path on a box with fewer GPUs than ranks) are staged through the host."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, h_in, group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 class ShardedRecommender:
     def __init__(self, rec, rank: int, world: int, shard_offset: int, group: Optional[dist.ProcessGroup] = None,
                  engine=None):
@@ -87,7 +98,7 @@ class ShardedRecommender:
         buf[:B * k * 4].view(torch.float32).copy_(scores.reshape(-1))
         buf[s_bytes:].view(torch.int64).copy_(pos.reshape(-1))
         gathered = torch.empty(chunk * self.world, dtype=torch.uint8, device=scores.device)
-        dist.all_gather_into_tensor(gathered, buf, group=self.group)          # ONE collective per step
+        all_gather_bytes(gathered, buf, self.group)                           # ONE collective per step
         q0, nq = user_slice(B, self.rank, self.world)
         cand_scores, cand_pos = self.engine.merge(gathered, self.world, B, k, q0, nq)
         out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
@@ -104,9 +115,9 @@ class ShardedRecommender:
         if B % self.world:
             raise ValueError("recommend_all needs n_users divisible by the world size")
         ids = torch.empty((B, top_k), dtype=torch.int64, device=out["ad_ids"].device)
-        dist.all_gather_into_tensor(ids, out["ad_ids"].contiguous(), group=self.group)
+        all_gather_bytes(ids, out["ad_ids"].contiguous(), self.group)
         sc = out["scores"]                                                    # [T, nq, top_k]
         T = sc.shape[0]
         sc_all = torch.empty((self.world, T, B // self.world, top_k), dtype=sc.dtype, device=sc.device)
-        dist.all_gather_into_tensor(sc_all, sc.contiguous(), group=self.group)
+        all_gather_bytes(sc_all, sc.contiguous(), self.group)
         return {"ad_ids": ids, "scores": sc_all.permute(1, 0, 2, 3).reshape(T, B, top_k), "tasks": out["tasks"]}
