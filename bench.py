@@ -197,7 +197,7 @@ def main():
         kernels = {k: {"ms_per_step": round(v["total_ms"] / args.steps, 3),
                        "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None,
                        "launches_per_step": v["launches"] / args.steps} for k, v in sorted(prof.items())}
-        sf = prof.get("search_filter_256x256")
+        sf = next((v for k, v in prof.items() if k.startswith("search_filter")), None)
         search = None
         if sf:
             ms = sf["total_ms"] / sf["launches"]

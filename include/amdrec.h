@@ -94,7 +94,10 @@ int amdrec_tower_forward(const amdrec_tower_params* p /*host*/, const int64_t* c
  * are not parameters here.  pos[0] is folded into b_proj and cross weights are passed
  * transposed ([out][in]) by the host. */
 typedef struct {
-    const float *w_v, *b_v, *w_o, *b_o;   /* [d_model][ldw_dm] */
+    /* [d_model][ldw_dm].  w_v may be NULL: then w_o / b_o hold the pre-multiplied W_o*W_v and
+     * W_o*b_v + b_o (exact algebra at seq_len 1; only the fp32 rounding order differs) and the
+     * attention block is ONE GEMM. */
+    const float *w_v, *b_v, *w_o, *b_o;
     const float *ln1_g, *ln1_b;
     const float *w_1, *b_1;               /* [d_ff][ldw_dm] */
     const float *w_2, *b_2;               /* [d_model][ldw_ff] */

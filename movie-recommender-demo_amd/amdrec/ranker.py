@@ -77,16 +77,19 @@ class TransformerRanker(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self._user_names, self._ad_names, self._n_num = list(user_feature_dims), list(ad_feature_dims), numerical_dim
         self._packed = None
+        # W_ov = W_o W_v pre-multiplied on the host (exact algebra at seq_len 1; set False to run the two
+        # GEMMs in the reference's order)
+        self.fuse_attention = True
 
     # -- packing ----------------------------------------------------------------------
     def invalidate(self):
         self._packed = None
 
     def _pack(self, device):
-        key = (str(device), tuple(p._version for p in self.parameters()))
+        key = (str(device), self.fuse_attention, tuple(p._version for p in self.parameters()))
         if self._packed is None or self._packed[0] != key:
             params, keep, tasks = weights.pack_ranker(self.state_dict(), self._user_names, self._ad_names,
-                                                      self._n_num, device)
+                                                      self._n_num, device, fuse_attention=self.fuse_attention)
             self._packed = (key, params, keep, tasks)
         return self._packed[1], self._packed[3]
 

@@ -122,8 +122,12 @@ def pack_tower(sd: Dict, prefix: str, feature_names: List[str], n_num: int, devi
     return p, pk
 
 
-def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int, device, ln_eps=1e-5):
-    """state_dict-like of the reference TransformerRanker -> (RankerParams, Packed)."""
+def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int, device, ln_eps=1e-5,
+                fuse_attention: bool = True):
+    """state_dict-like of the reference TransformerRanker -> (RankerParams, Packed, task names).
+    ``fuse_attention``: pre-multiply W_ov = W_o W_v, b_ov = W_o b_v + b_o in float64 (the seq-len-1
+    attention is exactly W_o(W_v x + b_v) + b_o, transformer_ranker.py:59-88 with :358), so each
+    encoder layer's attention block is one GEMM instead of two."""
     pk = Packed(device)
     tables = [sd[f"user_embeddings.{n}.weight"] for n in user_names] + \
              [sd[f"ad_embeddings.{n}.weight"] for n in ad_names]
@@ -145,15 +149,24 @@ def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int
     while f"transformer_layers.{l}.norm1.weight" in sd:
         pre = f"transformer_layers.{l}"
         L = p.layers[l]
-        for dst, src in (("w_v", "self_attention.W_v"), ("w_o", "self_attention.W_o"), ("w_1", "feed_forward.fc1")):
-            w, ld = _pad_k(_np64(sd[f"{pre}.{src}.weight"]))
+        wv, bv = _np64(sd[f"{pre}.self_attention.W_v.weight"]), _np64(sd[f"{pre}.self_attention.W_v.bias"])
+        wo, bo = _np64(sd[f"{pre}.self_attention.W_o.weight"]), _np64(sd[f"{pre}.self_attention.W_o.bias"])
+        if fuse_attention:
+            mats = (("w_o", wo @ wv), ("w_1", _np64(sd[f"{pre}.feed_forward.fc1.weight"])))
+            bo = wo @ bv + bo
+            L.w_v, L.b_v = None, None
+        else:
+            mats = (("w_v", wv), ("w_o", wo), ("w_1", _np64(sd[f"{pre}.feed_forward.fc1.weight"])))
+            L.b_v = pk.ptr(bv.astype(np.float32))
+        for dst, mat in mats:
+            w, ld = _pad_k(mat)
             setattr(L, dst, pk.ptr(w))
             L.ldw_dm = ld
+        L.b_o = pk.ptr(bo.astype(np.float32))
         w, L.ldw_ff = _pad_k(_np64(sd[f"{pre}.feed_forward.fc2.weight"]))
         L.w_2 = pk.ptr(w)
         p.d_ff = int(sd[f"{pre}.feed_forward.fc1.weight"].shape[0])
-        for dst, src in (("b_v", "self_attention.W_v.bias"), ("b_o", "self_attention.W_o.bias"),
-                         ("b_1", "feed_forward.fc1.bias"), ("b_2", "feed_forward.fc2.bias"),
+        for dst, src in (("b_1", "feed_forward.fc1.bias"), ("b_2", "feed_forward.fc2.bias"),
                          ("ln1_g", "norm1.weight"), ("ln1_b", "norm1.bias"),
                          ("ln2_g", "norm2.weight"), ("ln2_b", "norm2.bias")):
             setattr(L, dst, pk.ptr(_np64(sd[f"{pre}.{src}"]).astype(np.float32)))

@@ -8,10 +8,10 @@
 //  * v_mfma_f32_32x32x2_f32: exact fp32 (fmaf chain), 64 FLOP/clk/SIMD = the fp32 peak.
 //    A operand: lane l holds P[p = l&31][k = l>>5]; B operand: Q[q = l&31][k = l>>5].
 //    C/D: lane&31 = q column, row p = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-//  * 512-thread workgroups = 8 waves = 2 per SIMD, arranged WP x WQ; each wave owns
-//    TP x TQ tiles of 32x32 (acc in VGPRs: 16*TP*TQ per lane).
+//  * workgroups of WP x WQ waves (4 waves in every shape used), each wave owns TP x TQ tiles of
+//    32x32 (acc in VGPRs: 16*TP*TQ per lane); two workgroups per CU = 2 waves per SIMD.
 //  * Operands are staged global -> registers -> LDS in full 128-byte row segments
-//    (BK = 32 floats), double-buffered, one barrier per K-step.  The LDS image is
+//    (BK = 32 floats); the next tile's global loads are in flight under the current tile's MFMAs.  The LDS image is
 //    [row][32 floats] with the 16-byte chunk index XOR-swizzled by (row>>1)&7 so that a
 //    fragment read (ds_read_b128, 16-lane groups of distinct rows, same chunk) is
 //    bank-conflict free (guide §2 LDS, T2).
@@ -25,7 +25,6 @@
 namespace amdrec {
 
 constexpr int BK = 32;          // floats per K-step
-constexpr int NTHREADS = 512;   // 8 waves
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) {
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);   // float index
@@ -45,10 +44,14 @@ struct DenseRows {
     __device__ __forceinline__ long long map(long long r) const {
         return ((r >> gshift) * gstride) + (r & ((1ll << gshift) - 1));
     }
+    // Branch-free staging: rows past the end are CLAMPED to the last row (their accumulator rows are
+    // never stored or emitted: every epilogue guards on the row index), the K-range test is the same for
+    // all rows of a K-step and is hoisted by the caller (k_valid).  Requires rows >= 1.
+    __device__ __forceinline__ bool k_valid(int k) const { return k < K; }
     __device__ __forceinline__ f32x4 load(long long r, int k) const {
         long long a = map(r);
-        if (a < rows && k < K) return *reinterpret_cast<const f32x4*>(base + a * ld + k);
-        return f32x4{0.f, 0.f, 0.f, 0.f};
+        a = a < rows ? a : rows - 1;
+        return *reinterpret_cast<const f32x4*>(base + a * ld + k);
     }
 };
 
@@ -73,9 +76,10 @@ struct EmbConcatRows {
     int F, F0, E, eshift;       // E == 1 << eshift
     int n_num;
     int cat0_rowdiv;            // > 1: one user row broadcast over cat0_rowdiv candidate rows
+    __device__ __forceinline__ bool k_valid(int) const { return true; }   // the K tail is handled per segment
     __device__ __forceinline__ f32x4 load(long long r, int k) const {
         f32x4 z{0.f, 0.f, 0.f, 0.f};
-        if (r >= rows) return z;
+        r = r < rows ? r : rows - 1;              // clamped (see DenseRows::load)
         const long long gr = row_base + r;
         const int fe = F << eshift;
         if (k < fe) {
@@ -121,20 +125,32 @@ struct TileMap {
     int grid() const { return ((tiles_big + 7) / 8) * 8 * tiles_small; }
 };
 
-template <int WP_, int WQ_, int TP_, int TQ_>
+// WP x WQ waves per workgroup, TP x TQ 32x32 tiles per wave.  DBUF = double-buffered LDS (one barrier per
+// K-step, LDS 2x) or single-buffered (two barriers per K-step, half the LDS -> more workgroups per CU).
+// The shapes used are 4 waves / single buffer (<= 48 KB LDS, <= 256 VGPRs): TWO independent workgroups
+// per CU, so one workgroup's prologue (first HBM fetch) and epilogue (stores, residual loads, reductions)
+// run under the other's MFMAs.  Measured on the 8-wave / 128 KB / one-per-CU predecessor: MFMA pipe busy
+// 0.60-0.75, falling with epilogue weight (rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES; profiles/README.md).
+template <int WP_, int WQ_, int TP_, int TQ_, bool DBUF_ = false>
 struct Shape {
     static constexpr int WP = WP_, WQ = WQ_, TP = TP_, TQ = TQ_;
+    static constexpr bool DBUF = DBUF_;
+    static constexpr int NT = 64 * WP * WQ;
     static constexpr int BP = WP * TP * 32, BQ = WQ * TQ * 32;
     static constexpr int STAGE_FLOATS = (BP + BQ) * BK;
-    static constexpr size_t LDS_BYTES = 2ull * STAGE_FLOATS * sizeof(float);
-    static_assert(WP * WQ == 8, "8 waves per workgroup");
+    static constexpr size_t LDS_BYTES = (DBUF ? 2ull : 1ull) * STAGE_FLOATS * sizeof(float);
+    static constexpr int ROWS_PER_PASS = NT / 8;     // 8 x 16-byte chunks per 128-byte row segment
+    static_assert(BP % ROWS_PER_PASS == 0 && BQ % ROWS_PER_PASS == 0, "tile rows must fill whole staging passes");
 };
 
 // Accumulator tile set of one wave and where it sits in the output.
-template <int TP, int TQ>
+template <int TP_, int TQ_, int WP_, int WQ_>
 struct Acc {
+    static constexpr int TP = TP_, TQ = TQ_, WP = WP_, WQ = WQ_;
+    static constexpr int BQ = WQ * TQ * 32;
     f32x16 v[TP][TQ];
     int p0, q0;   // global p / q index of the wave's first row / column
+    int wp, wq;   // wave coordinates inside the workgroup
     // p index of register r in tile tp, q index of this lane in tile tq
     __device__ __forceinline__ int p(int tp, int r, int lane) const {
         return p0 + tp * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -144,8 +160,7 @@ struct Acc {
 
 // The mainloop.  P_IS_SMALL: which operand the TileMap's "small" index addresses.
 template <class S, bool P_IS_SMALL, class LoadP, class LoadQ, class Epi>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(LoadP lp, LoadQ lq, Epi epi, int ksteps,
-                                                           TileMap tm) {
+__global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(LoadP lp, LoadQ lq, Epi epi, int ksteps, TileMap tm) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TP = S::TP, TQ = S::TQ, BP = S::BP, BQ = S::BQ;
     int small, big;
@@ -159,42 +174,43 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
     const int lane = tid & 63, wave = tid >> 6;
     const int wp = wave / S::WQ, wq = wave % S::WQ;
 
-    // staging assignment: thread handles 16-B chunk (tid&7) of rows (tid>>3) + 64*u
+    // staging assignment: thread handles 16-B chunk (tid&7) of rows (tid>>3) + ROWS_PER_PASS*u
     const int srow = tid >> 3, schunk = tid & 7;
-    constexpr int NP = (BP + 63) / 64, NQ = (BQ + 63) / 64;
+    constexpr int RPP = S::ROWS_PER_PASS;
+    constexpr int NP = BP / RPP, NQ = BQ / RPP;
     f32x4 rp[NP], rq[NQ];
 
     auto stage_load = [&](int kt) {
         const int k = kt * BK + schunk * 4;
+        if (lp.k_valid(k)) {
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            int r = srow + 64 * u;
-            if (BP % 64 == 0 || r < BP) rp[u] = lp.load(prow0 + r, k);
+            for (int u = 0; u < NP; ++u) rp[u] = lp.load(prow0 + srow + RPP * u, k);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) rp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (lq.k_valid(k)) {
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) {
-            int r = srow + 64 * u;
-            if (BQ % 64 == 0 || r < BQ) rq[u] = lq.load(qrow0 + r, k);
+            for (int u = 0; u < NQ; ++u) rq[u] = lq.load(qrow0 + srow + RPP * u, k);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) rq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stage_store = [&](int buf) {
         float* sp = smem + buf * S::STAGE_FLOATS;
         float* sq = sp + BP * BK;
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            int r = srow + 64 * u;
-            if (BP % 64 == 0 || r < BP) *reinterpret_cast<f32x4*>(sp + lds_slot(r, schunk)) = rp[u];
-        }
+        for (int u = 0; u < NP; ++u) *reinterpret_cast<f32x4*>(sp + lds_slot(srow + RPP * u, schunk)) = rp[u];
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) {
-            int r = srow + 64 * u;
-            if (BQ % 64 == 0 || r < BQ) *reinterpret_cast<f32x4*>(sq + lds_slot(r, schunk)) = rq[u];
-        }
+        for (int u = 0; u < NQ; ++u) *reinterpret_cast<f32x4*>(sq + lds_slot(srow + RPP * u, schunk)) = rq[u];
     };
 
-    Acc<TP, TQ> acc;
+    Acc<TP, TQ, S::WP, S::WQ> acc;
     acc.p0 = (int)prow0 + wp * TP * 32;   // NOTE: int indices: streamed dims stay < 2^31 rows
     acc.q0 = (int)qrow0 + wq * TQ * 32;
+    acc.wp = wp;
+    acc.wq = wq;
 #pragma unroll
     for (int i = 0; i < TP; ++i)
 #pragma unroll
@@ -209,9 +225,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
     const int frow = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < ksteps; ++kt) {
         const bool more = kt + 1 < ksteps;
-        if (more) stage_load(kt + 1);
-        const float* sp = smem + (kt & 1) * S::STAGE_FLOATS + (wp * TP * 32) * BK;
-        const float* sq = smem + (kt & 1) * S::STAGE_FLOATS + BP * BK + (wq * TQ * 32) * BK;
+        if (more) stage_load(kt + 1);      // global -> registers, in flight under this K-step's MFMAs
+        const int buf = S::DBUF ? (kt & 1) : 0;
+        const float* sp = smem + buf * S::STAGE_FLOATS + (wp * TP * 32) * BK;
+        const float* sq = smem + buf * S::STAGE_FLOATS + BP * BK + (wq * TQ * 32) * BK;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             f32x4 a[TP], b[TQ];
@@ -230,8 +247,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
                         acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s],
                                                                            acc.v[i][j], 0, 0, 0);
         }
-        if (more) stage_store((kt + 1) & 1);
-        __syncthreads();
+        if (S::DBUF) {
+            if (more) stage_store((kt + 1) & 1);
+            __syncthreads();
+        } else {
+            __syncthreads();               // every wave has read this tile
+            if (more) {
+                stage_store(0);
+                __syncthreads();
+            }
+        }
     }
     epi(acc, smem);
 }
@@ -260,7 +285,7 @@ inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, 
     ProfScope prof(tag, 2.0 * (double)p_rows * (double)q_rows * ka,
                    4.0 * ((double)p_rows * ka + (double)q_rows * ka + Epi::out_bytes_per_elem * (double)p_rows * (double)q_rows),
                    stream);
-    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(NTHREADS), S::LDS_BYTES, stream, lp, lq, epi, ksteps, tm);
+    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(S::NT), S::LDS_BYTES, stream, lp, lq, epi, ksteps, tm);
     return hipGetLastError();
 }
 

@@ -14,11 +14,19 @@
 
 namespace amdrec {
 
-using ShapeWide = Shape<2, 4, 4, 2>;    // 256 features x 256 rows per block
-using ShapeNarrow = Shape<2, 4, 1, 2>;  //  64 features x 256 rows per block
+using ShapeWide = Shape<2, 2, 4, 2>;    // 256 features x 128 rows per workgroup (4 waves)
+using ShapeNarrow = Shape<2, 2, 1, 4>;  //  64 features x 256 rows per workgroup
+
+// Epilogue addressing: a lane owns output row q(j) and, per tile i and register group g, the 4
+// consecutive features f0 + 32*i + 8*g + {0..3} with f0 = p(0, 0, lane).  Every access is written as
+// (one base pointer per row/array) + (compile-time constant), so the constant folds into the
+// instruction's immediate offset and no per-access 64-bit address is kept live.
+#define AMDREC_EPI_FENCE() asm volatile("" ::: "memory")   // bounds the loads in flight (register pressure)
+#define FOFF(i, g) ((i) * 32 + (g) * 8)
 
 // out[row][f] = act(acc + bias[f])
-struct EpiLinear {
+template <bool FULL>
+struct EpiLinearT {
     static constexpr const char* name = "linear";
     static constexpr double out_bytes_per_elem = 1.0;
     const float* bias;
@@ -27,34 +35,43 @@ struct EpiLinear {
     long long rows;
     int nout;
     int relu;
-    template <int TP, int TQ>
-    __device__ void operator()(Acc<TP, TQ>& acc, float*) const {
+    template <class A>
+    __device__ void operator()(A& acc, float*) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
         const int lane = threadIdx.x & 63;
+        const int f0 = acc.p(0, 0, lane);
+        const float* bp = bias + f0;
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) {
-            const long long row = acc.q(j, lane);
-            if (row >= rows) continue;
+        for (int i = 0; i < TP; ++i) {
+            f32x4 b[4];
 #pragma unroll
-            for (int i = 0; i < TP; ++i)
+            for (int g = 0; g < 4; ++g)
+                b[g] = (FULL || f0 + FOFF(i, g) < nout) ? *reinterpret_cast<const f32x4*>(bp + FOFF(i, g))
+                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+                const long long row = acc.q(j, lane);
+                if (row >= rows) continue;
+                float* op = out + row * ldo + f0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int f = acc.p(i, 4 * g, lane);
-                    if (f >= nout) continue;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f);
+                    if (!FULL && f0 + FOFF(i, g) >= nout) continue;
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = acc.v[i][j][4 * g + e] + b[e];
+                        float x = acc.v[i][j][4 * g + e] + b[g][e];
                         v[e] = relu ? fmaxf(x, 0.f) : x;
                     }
-                    *reinterpret_cast<f32x4*>(out + row * ldo + f) = v;
+                    *reinterpret_cast<f32x4*>(op + FOFF(i, g)) = v;
                 }
+            }
         }
     }
 };
 
 // out[row][f] = x0[row][f] * (acc + bias[f]) + xl[row][f]     (FeatureInteractionLayer :201)
-struct EpiCross {
+template <bool FULL>
+struct EpiCrossT {
     static constexpr const char* name = "cross";
     static constexpr double out_bytes_per_elem = 1.0;
     const float* bias;
@@ -64,54 +81,63 @@ struct EpiCross {
     long long ld;
     long long rows;
     int nout;
-    template <int TP, int TQ>
-    __device__ void operator()(Acc<TP, TQ>& acc, float*) const {
+    template <class A>
+    __device__ void operator()(A& acc, float*) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
         const int lane = threadIdx.x & 63;
+        const int f0 = acc.p(0, 0, lane);
+        const float* bp = bias + f0;
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
             const long long row = acc.q(j, lane);
-            if (row >= rows) continue;
+            const bool rv = row < rows;
+            const long long ro = (rv ? row : rows - 1) * ld + f0;      // clamped: loads stay branch-free
+            const float* p0 = x0 + ro;
+            const float* pl = xl + ro;
+            float* op = out + ro;
 #pragma unroll
-            for (int i = 0; i < TP; ++i)
+            for (int i = 0; i < TP; ++i) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int f = acc.p(i, 4 * g, lane);
-                    if (f >= nout) continue;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f);
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(x0 + row * ld + f);
-                    const f32x4 al = *reinterpret_cast<const f32x4*>(xl + row * ld + f);
+                    if (!FULL && f0 + FOFF(i, g) >= nout) continue;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bp + FOFF(i, g));
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + FOFF(i, g));
+                    const f32x4 al = *reinterpret_cast<const f32x4*>(pl + FOFF(i, g));
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = a0[e] * (acc.v[i][j][4 * g + e] + b[e]) + al[e];
-                    *reinterpret_cast<f32x4*>(out + row * ld + f) = v;
+                    if (rv) *reinterpret_cast<f32x4*>(op + FOFF(i, g)) = v;
                 }
+                AMDREC_EPI_FENCE();
+            }
         }
     }
 };
 
-// Row statistics over the nout (<= 256) features of a row.  The block is one P tile wide
+// Row statistics over the nout (<= 256) features of a row.  The workgroup is one P tile wide
 // (ShapeWide: 2 waves x 128 features), so: in-lane sum over the lane's 64 values, exchange
 // with lane^32 (other row-group half of the same tiles), exchange between the 2 feature
-// waves through LDS.  `red` is [2 phases][2 wp][256 rows].
-template <int TP, int TQ>
+// waves through LDS.  `red` is [2 phases][2 wp][BQ rows].
+template <int TQ, int BQ>
 __device__ __forceinline__ void row_allreduce(float (&part)[TQ], float* red, int phase, int wp, int wq, int lane) {
 #pragma unroll
     for (int j = 0; j < TQ; ++j) part[j] += __shfl_xor(part[j], 32, 64);
-    float* r = red + phase * 512;
+    float* r = red + phase * 2 * BQ;
     if (lane < 32) {
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) r[wp * 256 + wq * TQ * 32 + j * 32 + lane] = part[j];
+        for (int j = 0; j < TQ; ++j) r[wp * BQ + wq * TQ * 32 + j * 32 + lane] = part[j];
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TQ; ++j) {
         int idx = wq * TQ * 32 + j * 32 + (lane & 31);
-        part[j] = r[idx] + r[256 + idx];
+        part[j] = r[idx] + r[BQ + idx];
     }
 }
 
 // out = LayerNorm(resid + acc + bias) * gamma + beta   (transformer_ranker.py:149, :153; eps 1e-5)
-struct EpiResidualLN {
+template <bool FULL>
+struct EpiResidualLNT {
     static constexpr const char* name = "residual_ln";
     static constexpr double out_bytes_per_elem = 1.0;
     const float* bias;
@@ -123,36 +149,44 @@ struct EpiResidualLN {
     long long rows;
     int nout;
     float eps;
-    template <int TP, int TQ>
-    __device__ void operator()(Acc<TP, TQ>& acc, float* smem) const {
-        static_assert(TP == 4 && TQ == 2, "LayerNorm epilogue is written for ShapeWide");
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int wp = wave / 4, wq = wave % 4;
+    template <class A>
+    __device__ void operator()(A& acc, float* smem) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
+        static_assert(A::WP == 2, "LayerNorm epilogue: two feature waves per row");
+        const int lane = threadIdx.x & 63;
+        const int wp = acc.wp, wq = acc.wq;
+        const int f0 = acc.p(0, 0, lane);
+        const float* bp = bias + f0;
         float s[TQ];
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) {
-            const long long row = acc.q(j, lane);
-            const bool rv = row < rows;
-            float a = 0.f;
+        for (int j = 0; j < TQ; ++j) s[j] = 0.f;
 #pragma unroll
-            for (int i = 0; i < TP; ++i)
+        for (int i = 0; i < TP; ++i) {
+            f32x4 b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b[g] = (FULL || f0 + FOFF(i, g) < nout) ? *reinterpret_cast<const f32x4*>(bp + FOFF(i, g))
+                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+                const long long row = acc.q(j, lane);
+                const float* rp = resid + (row < rows ? row : rows - 1) * ld + f0;   // clamped: loads stay branch-free
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int f = acc.p(i, 4 * g, lane);
-                    f32x4 b{0.f, 0.f, 0.f, 0.f}, rs{0.f, 0.f, 0.f, 0.f};
-                    const bool fv = f < nout;
-                    if (fv) b = *reinterpret_cast<const f32x4*>(bias + f);
-                    if (fv && rv) rs = *reinterpret_cast<const f32x4*>(resid + row * ld + f);
+                    const bool fv = FULL || f0 + FOFF(i, g) < nout;
+                    const f32x4 rs = fv ? *reinterpret_cast<const f32x4*>(rp + FOFF(i, g))
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = fv ? acc.v[i][j][4 * g + e] + b[e] + rs[e] : 0.f;
+                        float x = fv ? acc.v[i][j][4 * g + e] + b[g][e] + rs[e] : 0.f;
                         acc.v[i][j][4 * g + e] = x;
-                        a += x;
+                        s[j] += x;
                     }
                 }
-            s[j] = a;
+            }
+            AMDREC_EPI_FENCE();
         }
-        row_allreduce<TP, TQ>(s, smem, 0, wp, wq, lane);
+        row_allreduce<TQ, A::BQ>(s, smem, 0, wp, wq, lane);
         const float inv_n = 1.0f / (float)nout;
         float mean[TQ], q2[TQ];
 #pragma unroll
@@ -162,38 +196,54 @@ struct EpiResidualLN {
 #pragma unroll
             for (int i = 0; i < TP; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int f = acc.p(i, r, lane);
-                    float dlt = (f < nout) ? acc.v[i][j][r] - mean[j] : 0.f;
-                    a += dlt * dlt;
+                for (int g = 0; g < 4; ++g) {
+                    const bool fv = FULL || f0 + FOFF(i, g) < nout;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float dlt = fv ? acc.v[i][j][4 * g + e] - mean[j] : 0.f;
+                        a += dlt * dlt;
+                    }
                 }
             q2[j] = a;
         }
-        row_allreduce<TP, TQ>(q2, smem, 1, wp, wq, lane);
+        row_allreduce<TQ, A::BQ>(q2, smem, 1, wp, wq, lane);
+        float rstd[TQ];
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) {
-            const long long row = acc.q(j, lane);
-            if (row >= rows) continue;
-            const float rstd = 1.0f / sqrtf(q2[j] * inv_n + eps);
+        for (int j = 0; j < TQ; ++j) rstd[j] = 1.0f / sqrtf(q2[j] * inv_n + eps);
+        const float* gp = gamma + f0;
+        const float* tp = beta + f0;
 #pragma unroll
-            for (int i = 0; i < TP; ++i)
+        for (int i = 0; i < TP; ++i) {
+            f32x4 ga[4], be[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bool fv = FULL || f0 + FOFF(i, g) < nout;
+                ga[g] = fv ? *reinterpret_cast<const f32x4*>(gp + FOFF(i, g)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                be[g] = fv ? *reinterpret_cast<const f32x4*>(tp + FOFF(i, g)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+                const long long row = acc.q(j, lane);
+                if (row >= rows) continue;
+                float* op = out + row * ld + f0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int f = acc.p(i, 4 * g, lane);
-                    if (f >= nout) continue;
-                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + f);
-                    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + f);
+                    if (!FULL && f0 + FOFF(i, g) >= nout) continue;
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (acc.v[i][j][4 * g + e] - mean[j]) * rstd * ga[e] + be[e];
-                    *reinterpret_cast<f32x4*>(out + row * ld + f) = v;
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (acc.v[i][j][4 * g + e] - mean[j]) * rstd[j] * ga[g][e] + be[g][e];
+                    *reinterpret_cast<f32x4*>(op + FOFF(i, g)) = v;
                 }
+            }
+            AMDREC_EPI_FENCE();
         }
     }
 };
 
 // out = (acc + bias) / max(||acc + bias||_2, eps)      (F.normalize, two_tower_model.py:119)
-struct EpiL2Norm {
+template <bool FULL>
+struct EpiL2NormT {
     static constexpr const char* name = "l2norm";
     static constexpr double out_bytes_per_elem = 1.0;
     const float* bias;
@@ -202,48 +252,54 @@ struct EpiL2Norm {
     long long rows;
     int nout;
     float eps;
-    template <int TP, int TQ>
-    __device__ void operator()(Acc<TP, TQ>& acc, float* smem) const {
-        static_assert(TP == 4 && TQ == 2, "L2-norm epilogue is written for ShapeWide");
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int wp = wave / 4, wq = wave % 4;
+    template <class A>
+    __device__ void operator()(A& acc, float* smem) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
+        static_assert(A::WP == 2, "L2-norm epilogue: two feature waves per row");
+        const int lane = threadIdx.x & 63;
+        const int wp = acc.wp, wq = acc.wq;
+        const int f0 = acc.p(0, 0, lane);
+        const float* bp = bias + f0;
         float s[TQ];
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) {
-            float a = 0.f;
+        for (int j = 0; j < TQ; ++j) s[j] = 0.f;
 #pragma unroll
-            for (int i = 0; i < TP; ++i)
+        for (int i = 0; i < TP; ++i) {
+            f32x4 b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b[g] = (FULL || f0 + FOFF(i, g) < nout) ? *reinterpret_cast<const f32x4*>(bp + FOFF(i, g))
+                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TQ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int f = acc.p(i, 4 * g, lane);
-                    const bool fv = f < nout;
-                    f32x4 b{0.f, 0.f, 0.f, 0.f};
-                    if (fv) b = *reinterpret_cast<const f32x4*>(bias + f);
+                    const bool fv = FULL || f0 + FOFF(i, g) < nout;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = fv ? acc.v[i][j][4 * g + e] + b[e] : 0.f;
+                        float x = fv ? acc.v[i][j][4 * g + e] + b[g][e] : 0.f;
                         acc.v[i][j][4 * g + e] = x;
-                        a += x * x;
+                        s[j] += x * x;
                     }
                 }
-            s[j] = a;
+            AMDREC_EPI_FENCE();
         }
-        row_allreduce<TP, TQ>(s, smem, 0, wp, wq, lane);
+        row_allreduce<TQ, A::BQ>(s, smem, 0, wp, wq, lane);
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
             const long long row = acc.q(j, lane);
             if (row >= rows) continue;
             const float inv = 1.0f / fmaxf(sqrtf(s[j]), eps);
+            float* op = out + row * ldo + f0;
 #pragma unroll
             for (int i = 0; i < TP; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int f = acc.p(i, 4 * g, lane);
-                    if (f >= nout) continue;
+                    if (!FULL && f0 + FOFF(i, g) >= nout) continue;
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc.v[i][j][4 * g + e] * inv;
-                    *reinterpret_cast<f32x4*>(out + row * ldo + f) = v;
+                    *reinterpret_cast<f32x4*>(op + FOFF(i, g)) = v;
                 }
         }
     }
@@ -281,19 +337,25 @@ static inline DenseRows dense(const float* p, long long rows, long long ld, int 
     return DenseRows{p, rows, (int)ld, K, 30, 1ll << 30};
 }
 
-// y = epilogue(x W^T): dispatch on the output width
-template <class LoadQ, class Epi>
-static hipError_t linear(const float* W, int ldw, int nout, const LoadQ& lq, const Epi& epi, long long rows,
-                         hipStream_t st, int k_alg) {
+// y = epilogue(x W^T): dispatch on the output width; FULL = the width fills whole P tiles, so the
+// epilogue needs no feature-bound checks (true for every layer of the default architecture).
+template <template <bool> class EpiT, class LoadQ, class... EpiArgs>
+static hipError_t linear(const float* W, int ldw, int nout, const LoadQ& lq, long long rows, hipStream_t st,
+                         int k_alg, EpiArgs... ea) {
     DenseRows lp = dense(W, nout, ldw, ldw);
-    if (nout <= 64) return launch_gemm<ShapeNarrow, true>(lp, lq, epi, ldw, nout, rows, st, k_alg);
-    return launch_gemm<ShapeWide, true>(lp, lq, epi, ldw, nout, rows, st, k_alg);
+    if (nout <= 64) {
+        if (nout == ShapeNarrow::BP) return launch_gemm<ShapeNarrow, true>(lp, lq, EpiT<true>{ea...}, ldw, nout, rows, st, k_alg);
+        return launch_gemm<ShapeNarrow, true>(lp, lq, EpiT<false>{ea...}, ldw, nout, rows, st, k_alg);
+    }
+    if (nout % ShapeWide::BP == 0) return launch_gemm<ShapeWide, true>(lp, lq, EpiT<true>{ea...}, ldw, nout, rows, st, k_alg);
+    return launch_gemm<ShapeWide, true>(lp, lq, EpiT<false>{ea...}, ldw, nout, rows, st, k_alg);
 }
-template <class LoadQ, class Epi>
-static hipError_t linear_wide(const float* W, int ldw, int nout, const LoadQ& lq, const Epi& epi, long long rows,
-                              hipStream_t st, int k_alg) {
+template <template <bool> class EpiT, class LoadQ, class... EpiArgs>
+static hipError_t linear_wide(const float* W, int ldw, int nout, const LoadQ& lq, long long rows, hipStream_t st,
+                              int k_alg, EpiArgs... ea) {
     DenseRows lp = dense(W, nout, ldw, ldw);
-    return launch_gemm<ShapeWide, true>(lp, lq, epi, ldw, nout, rows, st, k_alg);
+    if (nout % ShapeWide::BP == 0) return launch_gemm<ShapeWide, true>(lp, lq, EpiT<true>{ea...}, ldw, nout, rows, st, k_alg);
+    return launch_gemm<ShapeWide, true>(lp, lq, EpiT<false>{ea...}, ldw, nout, rows, st, k_alg);
 }
 
 static inline int ilog2(int v) {
@@ -383,14 +445,17 @@ extern "C" int amdrec_tower_forward(const amdrec_tower_params* p, const int64_t*
             const int nout = p->dims[l + 1];
             hipError_t e;
             if (last) {
-                EpiL2Norm epi{p->b[l], out + r0 * ld_out, (long long)ld_out, m, nout, 1e-12f};
-                e = (l == 0) ? linear_wide(p->w[l], p->ldw[l], nout, g, epi, m, st, p->dims[l])
-                             : linear_wide(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), epi, m, st, p->dims[l]);
+                float* dst = out + r0 * ld_out;
+                e = (l == 0) ? linear_wide<EpiL2NormT>(p->w[l], p->ldw[l], nout, g, m, st, p->dims[l], p->b[l], dst,
+                                                       (long long)ld_out, m, nout, 1e-12f)
+                             : linear_wide<EpiL2NormT>(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), m, st,
+                                                       p->dims[l], p->b[l], dst, (long long)ld_out, m, nout, 1e-12f);
             } else {
                 float* dst = bufs[l & 1];
-                EpiLinear epi{p->b[l], dst, (long long)nout, m, nout, 1};
-                e = (l == 0) ? linear(p->w[l], p->ldw[l], nout, g, epi, m, st, p->dims[l])
-                             : linear(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), epi, m, st, p->dims[l]);
+                e = (l == 0) ? linear<EpiLinearT>(p->w[l], p->ldw[l], nout, g, m, st, p->dims[l], p->b[l], dst,
+                                                  (long long)nout, m, nout, 1)
+                             : linear<EpiLinearT>(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), m, st,
+                                                  p->dims[l], p->b[l], dst, (long long)nout, m, nout, 1);
                 cur = dst;
                 curw = nout;
             }
@@ -496,49 +561,50 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         g.rows1 = n_ad_rows > 0 ? n_ad_rows : 1;
         g.rows = m; g.F = F; g.F0 = F0; g.E = p->emb_dim; g.eshift = ilog2(p->emb_dim);
         g.n_num = p->n_num; g.cat0_rowdiv = (int)user_rowdiv;
-        {
-            EpiLinear epi{p->b_proj, X, (long long)dm, m, dm, 0};
-            HIP_TRY(linear_wide(p->w_proj, p->ldw_proj, dm, g, epi, m, st, F * p->emb_dim + p->n_num));
-        }
+        HIP_TRY(linear_wide<EpiLinearT>(p->w_proj, p->ldw_proj, dm, g, m, st, F * p->emb_dim + p->n_num,
+                                        p->b_proj, X, (long long)dm, m, dm, 0));
         // ---- encoder layers ----
         for (int l = 0; l < p->n_layers; ++l) {
             const amdrec_encoder_layer& L = p->layers[l];
-            {   // T = W_v x + b_v
-                EpiLinear epi{L.b_v, T, (long long)dm, m, dm, 0};
-                HIP_TRY(linear_wide(L.w_v, L.ldw_dm, dm, dense(X, m, dm, dm), epi, m, st, dm));
+            if (L.w_v != nullptr) {
+                // T = W_v x + b_v ; X = LN1(X + W_o T + b_o)
+                HIP_TRY(linear_wide<EpiLinearT>(L.w_v, L.ldw_dm, dm, dense(X, m, dm, dm), m, st, dm, L.b_v, T,
+                                                (long long)dm, m, dm, 0));
+                HIP_TRY(linear_wide<EpiResidualLNT>(L.w_o, L.ldw_dm, dm, dense(T, m, dm, dm), m, st, dm, L.b_o,
+                                                    (const float*)X, L.ln1_g, L.ln1_b, X, (long long)dm, m, dm,
+                                                    p->ln_eps));
+            } else {
+                // host pre-multiplied W_ov = W_o W_v: LN1(X + W_ov X + b_ov), written to the spare buffer
+                HIP_TRY(linear_wide<EpiResidualLNT>(L.w_o, L.ldw_dm, dm, dense(X, m, dm, dm), m, st, dm, L.b_o,
+                                                    (const float*)X, L.ln1_g, L.ln1_b, T, (long long)dm, m, dm,
+                                                    p->ln_eps));
+                float* tmp = X; X = T; T = tmp;
             }
-            {   // X = LN1(X + W_o T + b_o)
-                EpiResidualLN epi{L.b_o, X, L.ln1_g, L.ln1_b, X, (long long)dm, m, dm, p->ln_eps};
-                HIP_TRY(linear_wide(L.w_o, L.ldw_dm, dm, dense(T, m, dm, dm), epi, m, st, dm));
-            }
-            {   // H = relu(W_1 X + b_1)
-                EpiLinear epi{L.b_1, H, (long long)p->d_ff, m, p->d_ff, 1};
-                HIP_TRY(linear(L.w_1, L.ldw_dm, p->d_ff, dense(X, m, dm, dm), epi, m, st, dm));
-            }
-            {   // X = LN2(X + W_2 H + b_2)
-                EpiResidualLN epi{L.b_2, X, L.ln2_g, L.ln2_b, X, (long long)dm, m, dm, p->ln_eps};
-                HIP_TRY(linear_wide(L.w_2, L.ldw_ff, dm, dense(H, m, p->d_ff, p->d_ff), epi, m, st, p->d_ff));
-            }
+            // H = relu(W_1 X + b_1)
+            HIP_TRY(linear<EpiLinearT>(L.w_1, L.ldw_dm, p->d_ff, dense(X, m, dm, dm), m, st, dm, L.b_1, H,
+                                       (long long)p->d_ff, m, p->d_ff, 1));
+            // X = LN2(X + W_2 H + b_2)
+            HIP_TRY(linear_wide<EpiResidualLNT>(L.w_2, L.ldw_ff, dm, dense(H, m, p->d_ff, p->d_ff), m, st, p->d_ff,
+                                                L.b_2, (const float*)X, L.ln2_g, L.ln2_b, X, (long long)dm, m, dm,
+                                                p->ln_eps));
         }
         // ---- cross layers: xl <- x0 * (xl W_i + b_i) + xl ; x0 = X ----
         const float* xl = X;
         for (int c = 0; c < p->n_cross; ++c) {
             float* dst = (c & 1) ? X0 : T;
-            EpiCross epi{p->cross_b[c], X, xl, dst, (long long)dm, m, dm};
-            HIP_TRY(linear_wide(p->cross_wt[c], p->ldw_cross, dm, dense(xl, m, dm, dm), epi, m, st, dm));
+            HIP_TRY(linear_wide<EpiCrossT>(p->cross_wt[c], p->ldw_cross, dm, dense(xl, m, dm, dm), m, st, dm,
+                                           p->cross_b[c], (const float*)X, xl, dst, (long long)dm, m, dm));
             xl = dst;
         }
         // ---- heads ----
         const int h1 = p->head_h1, h2 = p->head_h2, nt = p->n_tasks;
         float* H1 = H;                                   // [m][nt*h1]
         float* H2 = H + (size_t)m * nt * h1;             // [m][nt*h2]
-        {
-            EpiLinear epi{p->head_b1, H1, (long long)nt * h1, m, nt * h1, 1};
-            HIP_TRY(linear(p->head_w1, p->ldw_head1, nt * h1, dense(xl, m, dm, dm), epi, m, st, dm));
-        }
+        HIP_TRY(linear<EpiLinearT>(p->head_w1, p->ldw_head1, nt * h1, dense(xl, m, dm, dm), m, st, dm, p->head_b1, H1,
+                                   (long long)nt * h1, m, nt * h1, 1));
         for (int t = 0; t < nt; ++t) {
-            EpiLinear epi{p->head_b2[t], H2 + t * h2, (long long)nt * h2, m, h2, 1};
-            HIP_TRY(linear(p->head_w2[t], p->ldw_head2, h2, dense(H1 + t * h1, m, (long long)nt * h1, h1), epi, m, st, h1));
+            HIP_TRY(linear<EpiLinearT>(p->head_w2[t], p->ldw_head2, h2, dense(H1 + t * h1, m, (long long)nt * h1, h1), m,
+                                       st, h1, p->head_b2[t], H2 + t * h2, (long long)nt * h2, m, h2, 1));
             hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, st,
                                H2 + t * h2, (long long)nt * h2, h2, p->head_w3[t], p->head_b3[t],
                                out_logits + (long long)t * ld_logits + r0, m);

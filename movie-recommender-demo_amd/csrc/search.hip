@@ -35,8 +35,9 @@ struct EpiStoreScores {
     int nq;
     long long n_sample;  // sample rows
     DenseRows map;       // to test validity of the mapped row
-    template <int TP, int TQ>
-    __device__ void operator()(Acc<TP, TQ>& acc, float*) const {
+    template <class A>
+    __device__ void operator()(A& acc, float*) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
@@ -68,8 +69,9 @@ struct EpiFilter {
     int* cnt;                    // [nq]
     int cap, nq;
     long long nrows;
-    template <int TP, int TQ>
-    __device__ void operator()(Acc<TP, TQ>& acc, float*) const {
+    template <class A>
+    __device__ void operator()(A& acc, float*) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
@@ -451,10 +453,10 @@ extern "C" int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld
 
     if (nrows > 0) {
         hipError_t e;
-        if (nq > 128)      e = run_passes<Shape<2, 4, 4, 2>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
-        else if (nq > 64)  e = run_passes<Shape<4, 2, 2, 2>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
-        else if (nq > 32)  e = run_passes<Shape<8, 1, 2, 2>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
-        else               e = run_passes<Shape<8, 1, 2, 1>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
+        // corpus tile 256 rows x query tile 128 / 64 / 32 (4 waves each)
+        if (nq > 64)       e = run_passes<Shape<2, 2, 4, 2>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
+        else if (nq > 32)  e = run_passes<Shape<4, 1, 2, 2>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
+        else               e = run_passes<Shape<4, 1, 2, 1>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
         HIP_TRY(e);
     }
     static bool attr_done = false;

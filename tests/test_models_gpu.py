@@ -100,6 +100,19 @@ def test_ranker_large_batch_vs_oracle(cross):
         assert ok, (cross, t, err)
 
 
+def test_ranker_unfused_attention_matches_too():
+    """fuse_attention=False runs W_v and W_o as two GEMMs in the reference's order."""
+    m, sd, _, batches = _ranker("demo", "scaled")
+    m.fuse_attention = False
+    g = load_golden("ranker_demo_scaled.npz")
+    B = 64
+    pred = m(_cu(g[f"B{B}_user_cat"]), _cu(g[f"B{B}_ad_cat"]), _cu(g[f"B{B}_user_num"]))
+    scale = cases.logit_scale({t: g[f"B{B}_{t}"] for t in pred})
+    for t in pred:
+        ok, err = cases.logit_close(pred[t].cpu().numpy(), g[f"B{B}_{t}"], scale=scale)
+        assert ok, (t, err)
+
+
 def test_ranker_score_candidates_broadcast_and_gather():
     m, sd, (user, ad, nnum), _ = _ranker("ragged", "scaled")
     U, k, N = 7, 500, 5000
