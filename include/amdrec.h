@@ -46,6 +46,23 @@ int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld_corpus, in
                        int64_t* out_pos /*[nq][k]*/, void* workspace, size_t workspace_bytes,
                        int* n_fixup, void* stream);
 
+/* ---- retrieval: IVF-Flat (faiss IndexIVFFlat, METRIC_INNER_PRODUCT, IndexFlatIP quantizer:
+ * faiss_retrieval.py:50-55, searched at :150-155 with index.nprobe = nprobe) ---------------------
+ * Layout: corpus rows stored list-contiguous `lists[N][ld]` (list l = rows [list_off[l], list_off[l+1]))
+ * with row_pos[r] = position of stored row r in insertion order.  A search is
+ *   1. amdrec_flat_search(centroids, nlist, ..., k = nprobe)  -> probes[nq][nprobe]  (-1 = none)
+ *   2. pool_base[q][p] = exclusive prefix sum of the probed lists' lengths (host-side plumbing)
+ *   3. amdrec_ivf_scan   -> pool_keys[q][pool_base[q][p] + i] = key(score, row_pos + pos_offset)
+ *   4. amdrec_ivf_select -> exact k best of each query's pool, (score desc, position asc).
+ * The scan is exact over the probed lists; which lists are probed depends on the trained centroids. */
+int amdrec_ivf_scan(const float* lists, int64_t ld, int dim, const int64_t* row_pos,
+                    const int64_t* list_off, const float* queries, int64_t nq, int64_t ld_queries,
+                    const int64_t* probes, const int64_t* pool_base, int nprobe, uint64_t* pool_keys,
+                    int64_t pool_ld, int64_t pos_offset, void* stream);
+int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count /*[nq]*/,
+                      int64_t nq, int k, float* out_scores /*[nq][k]*/, int64_t* out_pos /*[nq][k]*/,
+                      void* stream);
+
 /* Cross-shard merge (absent in the single-device reference): for queries
  * [q0, q0+nq) merge n_lists per-shard top-k lists (scores/positions of list g start
  * g*list_stride_bytes after the base pointers; each list is [nq_total][k]; positions are global,

@@ -197,7 +197,8 @@ class FAISSIndex:
         scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         pos = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         if self.index_type == "IVF":
-            self._ivf.search(self._xb, self._n, q, k, self.nprobe, scores, pos)
+            self._ivf.search(self._xb, self._n, q, k, self.nprobe, scores, pos,
+                             pos_offset=pos_offset if return_positions else 0)
         else:
             flat_search(self._xb, self._n, q, k, scores, pos, pos_offset=pos_offset if return_positions else 0)
         if return_positions or self._identity:

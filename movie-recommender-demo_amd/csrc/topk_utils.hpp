@@ -1,0 +1,74 @@
+// Block-wide selection helpers shared by the flat and IVF search kernels (LDS histograms for radix
+// select, bitonic sort of 64-bit keys, result write-out).
+#pragma once
+#include "common.hpp"
+
+namespace amdrec {
+
+// ---- block-wide helpers -------------------------------------------------------------
+// Find, scanning bins from the top, the bin that holds the r-th largest element.
+// hist[NB] in LDS; returns bin and updates r to the rank inside that bin.  All threads call.
+template <int NB, int NT>
+__device__ inline int find_bin_desc(const int* hist, int& r, int* scratch /*[NT+2]*/) {
+    constexpr int PER = NB / NT;
+    const int tid = threadIdx.x;
+    int local = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) local += hist[tid * PER + i];
+    scratch[tid] = local;
+    __syncthreads();
+    // serial suffix over NT partial sums by one wave-lane (NT <= 512: cheap)
+    if (tid == 0) {
+        int above = 0, found = -1, rr = r;
+        for (int t = NT - 1; t >= 0; --t) {
+            if (above + scratch[t] >= rr) { found = t; break; }
+            above += scratch[t];
+        }
+        int bin = -1;
+        if (found >= 0) {
+            for (int i = PER - 1; i >= 0; --i) {
+                int h = hist[found * PER + i];
+                if (above + h >= rr) { bin = found * PER + i; break; }
+                above += h;
+            }
+        }
+        scratch[NT] = bin;
+        scratch[NT + 1] = rr - above;
+    }
+    __syncthreads();
+    int bin = scratch[NT];
+    r = scratch[NT + 1];
+    __syncthreads();
+    return bin;
+}
+
+// Bitonic sort of P (power of two) 64-bit keys in LDS, descending.  All threads call.
+__device__ inline void bitonic_desc(unsigned long long* buf, int P) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int sz = 2; sz <= P; sz <<= 1) {
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = tid; i < P; i += nt) {
+                int j = i ^ st;
+                if (j > i) {
+                    unsigned long long a = buf[i], b = buf[j];
+                    bool desc = (i & sz) == 0;
+                    if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ inline void write_result(const unsigned long long* buf, int have, int k, long long q, float* outD,
+                                    long long* outI, long long pos_offset) {
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        unsigned long long key = (i < have) ? buf[i] : 0ull;
+        bool valid = key != 0ull;
+        outD[q * k + i] = valid ? key_score(key) : -INFINITY;
+        outI[q * k + i] = valid ? (long long)key_pos(key) + pos_offset : -1ll;
+    }
+}
+
+
+}  // namespace amdrec

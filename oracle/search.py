@@ -142,11 +142,15 @@ def assign_ip(x, cent, chunk=1 << 16):
     return out
 
 
-def ivf_search(xb, assign, cent, xq, k, nprobe):
-    """IndexIVFFlat(IP).search given centroids + assignments: exact scan of probed lists."""
+def ivf_search(xb, assign, cent, xq, k, nprobe, probes=None):
+    """IndexIVFFlat(IP).search given centroids + assignments: exact scan of probed lists.
+    ``probes`` [nq, nprobe] overrides the coarse selection (to test the scan in isolation)."""
     nq = xq.shape[0]
-    coarse = xq @ cent.T
-    _, probe = topk_desc(coarse.astype(np.float32), nprobe)
+    if probes is None:
+        coarse = xq @ cent.T
+        _, probe = topk_desc(coarse.astype(np.float32), nprobe)
+    else:
+        probe = np.asarray(probes)
     D = np.full((nq, k), -np.inf, dtype=np.float32)
     I = np.full((nq, k), -1, dtype=np.int64)
     lists = [np.nonzero(assign == c)[0] for c in range(cent.shape[0])]

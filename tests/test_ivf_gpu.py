@@ -1,0 +1,87 @@
+"""IVF-Flat on the GPU: (i) the scan is exact over the probed lists given this build's centroids
+and assignments (vs oracle.search.ivf_search), (ii) recall@k vs the Flat result, (iii) the
+FAISSIndex drop-in defaults (index_type='IVF', nlist=100, nprobe=10: faiss_retrieval.py:20-25)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from amdrec import synth
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _clustered(n, d, n_clusters, seed, spread=0.35):
+    rng = np.random.default_rng(seed)
+    c = rng.standard_normal((n_clusters, d)).astype(np.float32)
+    x = c[rng.integers(0, n_clusters, n)] + spread * rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("n,nlist,nprobe,k,nq", [(20_000, 100, 10, 100, 33), (50_000, 256, 16, 500, 64),
+                                                 (5_000, 64, 64, 50, 5)])
+def test_ivf_scan_is_exact_given_centroids(n, nlist, nprobe, k, nq):
+    from amdrec.index import FAISSIndex
+    xb = _clustered(n, 256, 40, 1)
+    xq = _clustered(nq, 256, 40, 2)
+    idx = FAISSIndex(256, index_type="IVF", nlist=nlist, nprobe=nprobe)
+    idx.add(xb)
+    assert idx.index.is_trained and idx.index.ntotal == n and idx.index.nprobe == nprobe
+    ids, D = idx.search(xq, k)
+    cent = idx._ivf.centroids.cpu().numpy()
+    assign = idx._ivf.assign.cpu().numpy()
+    xbn, xqn = oracle.search.normalize_l2(xb), oracle.search.normalize_l2(xq)
+    # the oracle with ITS OWN coarse selection (probes may differ only in coarse near-ties)
+    rD, rI = oracle.search.ivf_search(xbn, assign, cent, xqn, k, nprobe)
+    same = (ids == rI).all(axis=1)
+    assert same.mean() >= 0.9
+    assert np.abs(D[same] - rD[same]).max() <= cases.SCORE_ATOL
+    # the scan in isolation: feed the GPU's probes to the oracle -> must match for every query
+    cs = torch.empty((nq, nprobe), dtype=torch.float32, device="cuda")
+    pr = torch.empty((nq, nprobe), dtype=torch.int64, device="cuda")
+    from amdrec.index import flat_search
+    flat_search(idx._ivf.centroids, nlist, torch.from_numpy(xqn).cuda(), nprobe, cs, pr)
+    rD2, rI2 = oracle.search.ivf_search(xbn, assign, cent, xqn, k, nprobe, probes=pr.cpu().numpy())
+    oracle.search.check_topk(rD2, rI2, D, ids, tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
+    assert (ids == rI2).mean() > 0.999
+
+
+def test_ivf_full_probe_equals_flat_and_recall_grows_with_nprobe():
+    from amdrec.index import FAISSIndex
+    n, k = 60_000, 500
+    xb, xq = _clustered(n, 256, 64, 3), _clustered(48, 256, 64, 4)
+    flat = FAISSIndex(256, index_type="Flat")
+    flat.add(xb)
+    fids, fD = flat.search(xq, k)
+    ivf = FAISSIndex(256, index_type="IVF", nlist=128, nprobe=128)
+    ivf.add(xb)
+    ids, D = ivf.search(xq, k)                       # probing every list == exhaustive search
+    oracle.search.check_topk(fD, fids, D, ids, tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
+    recalls = []
+    for nprobe in (1, 4, 16, 64):
+        ivf.index.nprobe = nprobe                    # the reference sets index.nprobe before searching (:150-151)
+        ids, _ = ivf.search(xq, k)
+        recalls.append(np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, fids)]))
+    assert recalls == sorted(recalls) and recalls[-1] > 0.9
+    print("recall@500 vs Flat by nprobe (1,4,16,64):", [round(r, 3) for r in recalls])
+
+
+def test_ivf_defaults_underfill_and_save_load(tmp_path):
+    from amdrec.index import FAISSIndex
+    xb, xq = _clustered(3_000, 256, 20, 5), _clustered(4, 256, 20, 6)
+    idx = FAISSIndex(256)                             # reference defaults: IVF, nlist=100, nprobe=10
+    assert idx.index_type == "IVF" and not idx.index.is_trained
+    idx.add(xb[:2000])
+    idx.add(xb[2000:], ad_ids=list(range(10_000, 11_000)))    # second add: no re-training, custom ids
+    ids, D = idx.search(xq, 500)                      # ~300 rows in 10 lists < k=500 -> under-filled like faiss
+    filled = np.isfinite(D)
+    assert filled.sum(axis=1).min() < 500 and np.all(ids[~filled] == idx.id_map[-1])   # id_map[-1] (:159)
+    assert set(ids[filled].tolist()) <= set(range(2000)) | set(range(10_000, 11_000))
+    p = str(tmp_path / "ivf.bin")
+    idx.save(p)
+    idx2 = FAISSIndex(256)
+    idx2.load(p)
+    ids2, D2 = idx2.search(xq, 500)
+    assert np.array_equal(ids, ids2) and np.array_equal(D, D2)
+    assert idx2.get_stats() == idx.get_stats()
