@@ -182,20 +182,11 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
 
     auto stage_load = [&](int kt) {
         const int k = kt * BK + schunk * 4;
-        if (lp.k_valid(k)) {
+        const bool pv = lp.k_valid(k), qv = lq.k_valid(k);
 #pragma unroll
-            for (int u = 0; u < NP; ++u) rp[u] = lp.load(prow0 + srow + RPP * u, k);
-        } else {
+        for (int u = 0; u < NP; ++u) rp[u] = pv ? lp.load(prow0 + srow + RPP * u, k) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < NP; ++u) rp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (lq.k_valid(k)) {
-#pragma unroll
-            for (int u = 0; u < NQ; ++u) rq[u] = lq.load(qrow0 + srow + RPP * u, k);
-        } else {
-#pragma unroll
-            for (int u = 0; u < NQ; ++u) rq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int u = 0; u < NQ; ++u) rq[u] = qv ? lq.load(qrow0 + srow + RPP * u, k) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto stage_store = [&](int buf) {
         float* sp = smem + buf * S::STAGE_FLOATS;
@@ -225,12 +216,12 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
     const int frow = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < ksteps; ++kt) {
         const bool more = kt + 1 < ksteps;
-        if (more) stage_load(kt + 1);      // global -> registers, in flight under this K-step's MFMAs
         const int buf = S::DBUF ? (kt & 1) : 0;
         const float* sp = smem + buf * S::STAGE_FLOATS + (wp * TP * 32) * BK;
         const float* sq = smem + buf * S::STAGE_FLOATS + BP * BK + (wq * TQ * 32) * BK;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+            if (more && c == 0) stage_load(kt + 1);   // global -> registers, in flight under this K-step's MFMAs
             f32x4 a[TP], b[TQ];
 #pragma unroll
             for (int i = 0; i < TP; ++i)

@@ -17,12 +17,70 @@ namespace amdrec {
 using ShapeWide = Shape<2, 2, 4, 2>;    // 256 features x 128 rows per workgroup (4 waves)
 using ShapeNarrow = Shape<2, 2, 1, 4>;  //  64 features x 256 rows per workgroup
 
-// Epilogue addressing: a lane owns output row q(j) and, per tile i and register group g, the 4
-// consecutive features f0 + 32*i + 8*g + {0..3} with f0 = p(0, 0, lane).  Every access is written as
-// (one base pointer per row/array) + (compile-time constant), so the constant folds into the
-// instruction's immediate offset and no per-access 64-bit address is kept live.
+// Epilogue data movement.  In the accumulator a lane owns row q(j) and, per tile i and register group g,
+// the 4 consecutive features 32*i + 8*g + 4*(lane>>5) + {0..3}: a direct store instruction would cover
+// 32 rows x 32 bytes (quarter cache lines).  Instead every 32x32 tile goes through a wave-private 4 KB
+// LDS tile (16-byte chunk index XOR (row & 7): conflict-free both ways) so that each global store / load
+// instruction moves 8 rows x 128 bytes = whole cache lines (measured on the layer shapes: +4.5 % at
+// K = 1024, +5 % at K = 256, +7.5 % for the 1024-wide FFN output; tools/gemm_probe.hip).
+// LDS instructions of one wave execute in order, so the tile needs no barrier.
 #define AMDREC_EPI_FENCE() asm volatile("" ::: "memory")   // bounds the loads in flight (register pressure)
 #define FOFF(i, g) ((i) * 32 + (g) * 8)
+constexpr int EPI_TILE_FLOATS = 1024;        // 32 rows x 32 floats per wave
+constexpr int EPI_TILE_BASE = 1024;          // floats reserved below the tiles for row reductions
+
+struct WaveTile {
+    float* t;
+    int r, h, lr, lc;                         // acc view: row r, half h;  line view: row lr (+8*pass), chunk lc
+    __device__ __forceinline__ WaveTile(float* smem, int lane)
+        : t(smem + EPI_TILE_BASE + (threadIdx.x >> 6) * EPI_TILE_FLOATS), r(lane & 31), h(lane >> 5), lr(lane >> 3),
+          lc(lane & 7) {}
+    __device__ __forceinline__ void put_acc(const f32x4 (&v)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(t + r * 32 + (((2 * g + h) ^ (r & 7)) << 2)) = v[g];
+    }
+    __device__ __forceinline__ void get_acc(f32x4 (&v)[4]) const {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(t + r * 32 + (((2 * g + h) ^ (r & 7)) << 2));
+    }
+    __device__ __forceinline__ f32x4 get_line(int pass) const {
+        const int row = lr + 8 * pass;
+        return *reinterpret_cast<const f32x4*>(t + row * 32 + ((lc ^ (row & 7)) << 2));
+    }
+    __device__ __forceinline__ void put_line(int pass, f32x4 v) {
+        const int row = lr + 8 * pass;
+        *reinterpret_cast<f32x4*>(t + row * 32 + ((lc ^ (row & 7)) << 2)) = v;
+    }
+};
+
+// full-line store of one 32x32 tile held in acc layout `v`: rows row0.., features feat0..
+template <bool FULL>
+__device__ __forceinline__ void tile_store(WaveTile& wt, const f32x4 (&v)[4], float* out, long long ld, long long row0,
+                                           long long rows, int feat0, int nout) {
+    wt.put_acc(v);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const f32x4 line = wt.get_line(pass);
+        const long long row = row0 + wt.lr + 8 * pass;
+        const int f = feat0 + wt.lc * 4;
+        if (row < rows && (FULL || f < nout)) *reinterpret_cast<f32x4*>(out + row * ld + f) = line;
+    }
+}
+// full-line load of one 32x32 tile into acc layout (rows past the end are clamped, features masked)
+template <bool FULL>
+__device__ __forceinline__ void tile_load(WaveTile& wt, f32x4 (&v)[4], const float* src, long long ld, long long row0,
+                                          long long rows, int feat0, int nout) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        long long row = row0 + wt.lr + 8 * pass;
+        row = row < rows ? row : rows - 1;
+        const int f = feat0 + wt.lc * 4;
+        const f32x4 line = (FULL || f < nout) ? *reinterpret_cast<const f32x4*>(src + row * ld + f)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+        wt.put_line(pass, line);
+    }
+    wt.get_acc(v);
+}
 
 // out[row][f] = act(acc + bias[f])
 template <bool FULL>
@@ -36,9 +94,10 @@ struct EpiLinearT {
     int nout;
     int relu;
     template <class A>
-    __device__ void operator()(A& acc, float*) const {
+    __device__ void operator()(A& acc, float* smem) const {
         constexpr int TP = A::TP, TQ = A::TQ;
         const int lane = threadIdx.x & 63;
+        WaveTile wt(smem, lane);
         const int f0 = acc.p(0, 0, lane);
         const float* bp = bias + f0;
 #pragma unroll
@@ -50,20 +109,15 @@ struct EpiLinearT {
                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
-                const long long row = acc.q(j, lane);
-                if (row >= rows) continue;
-                float* op = out + row * ldo + f0;
+                f32x4 v[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (!FULL && f0 + FOFF(i, g) >= nout) continue;
-                    f32x4 v;
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = acc.v[i][j][4 * g + e] + b[g][e];
-                        v[e] = relu ? fmaxf(x, 0.f) : x;
+                        const float x = acc.v[i][j][4 * g + e] + b[g][e];
+                        v[g][e] = relu ? fmaxf(x, 0.f) : x;
                     }
-                    *reinterpret_cast<f32x4*>(op + FOFF(i, g)) = v;
-                }
+                tile_store<FULL>(wt, v, out, ldo, (long long)acc.q0 + j * 32, rows, acc.p0 + i * 32, nout);
             }
         }
     }
@@ -82,32 +136,30 @@ struct EpiCrossT {
     long long rows;
     int nout;
     template <class A>
-    __device__ void operator()(A& acc, float*) const {
+    __device__ void operator()(A& acc, float* smem) const {
         constexpr int TP = A::TP, TQ = A::TQ;
         const int lane = threadIdx.x & 63;
+        WaveTile wt(smem, lane);
         const int f0 = acc.p(0, 0, lane);
         const float* bp = bias + f0;
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) {
-            const long long row = acc.q(j, lane);
-            const bool rv = row < rows;
-            const long long ro = (rv ? row : rows - 1) * ld + f0;      // clamped: loads stay branch-free
-            const float* p0 = x0 + ro;
-            const float* pl = xl + ro;
-            float* op = out + ro;
+        for (int i = 0; i < TP; ++i) {
+            f32x4 b[4];
 #pragma unroll
-            for (int i = 0; i < TP; ++i) {
+            for (int g = 0; g < 4; ++g)
+                b[g] = (FULL || f0 + FOFF(i, g) < nout) ? *reinterpret_cast<const f32x4*>(bp + FOFF(i, g))
+                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (!FULL && f0 + FOFF(i, g) >= nout) continue;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bp + FOFF(i, g));
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + FOFF(i, g));
-                    const f32x4 al = *reinterpret_cast<const f32x4*>(pl + FOFF(i, g));
-                    f32x4 v;
+            for (int j = 0; j < TQ; ++j) {
+                const long long row0 = (long long)acc.q0 + j * 32;
+                f32x4 a0[4], al[4], v[4];
+                tile_load<FULL>(wt, a0, x0, ld, row0, rows, acc.p0 + i * 32, nout);
+                tile_load<FULL>(wt, al, xl, ld, row0, rows, acc.p0 + i * 32, nout);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = a0[e] * (acc.v[i][j][4 * g + e] + b[e]) + al[e];
-                    if (rv) *reinterpret_cast<f32x4*>(op + FOFF(i, g)) = v;
-                }
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = a0[g][e] * (acc.v[i][j][4 * g + e] + b[g][e]) + al[g][e];
+                tile_store<FULL>(wt, v, out, ld, row0, rows, acc.p0 + i * 32, nout);
                 AMDREC_EPI_FENCE();
             }
         }
@@ -117,9 +169,10 @@ struct EpiCrossT {
 // Row statistics over the nout (<= 256) features of a row.  The workgroup is one P tile wide
 // (ShapeWide: 2 waves x 128 features), so: in-lane sum over the lane's 64 values, exchange
 // with lane^32 (other row-group half of the same tiles), exchange between the 2 feature
-// waves through LDS.  `red` is [2 phases][2 wp][BQ rows].
+// waves through LDS.  `red` is [2 phases][2 wp][BQ rows] (<= EPI_TILE_BASE floats).
 template <int TQ, int BQ>
 __device__ __forceinline__ void row_allreduce(float (&part)[TQ], float* red, int phase, int wp, int wq, int lane) {
+    static_assert(4 * BQ <= EPI_TILE_BASE, "reduction scratch overlaps the epilogue tiles");
 #pragma unroll
     for (int j = 0; j < TQ; ++j) part[j] += __shfl_xor(part[j], 32, 64);
     float* r = red + phase * 2 * BQ;
@@ -155,6 +208,7 @@ struct EpiResidualLNT {
         static_assert(A::WP == 2, "LayerNorm epilogue: two feature waves per row");
         const int lane = threadIdx.x & 63;
         const int wp = acc.wp, wq = acc.wq;
+        WaveTile wt(smem, lane);
         const int f0 = acc.p(0, 0, lane);
         const float* bp = bias + f0;
         float s[TQ];
@@ -169,16 +223,14 @@ struct EpiResidualLNT {
                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
-                const long long row = acc.q(j, lane);
-                const float* rp = resid + (row < rows ? row : rows - 1) * ld + f0;   // clamped: loads stay branch-free
+                f32x4 rs[4];
+                tile_load<FULL>(wt, rs, resid, ld, (long long)acc.q0 + j * 32, rows, acc.p0 + i * 32, nout);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const bool fv = FULL || f0 + FOFF(i, g) < nout;
-                    const f32x4 rs = fv ? *reinterpret_cast<const f32x4*>(rp + FOFF(i, g))
-                                        : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = fv ? acc.v[i][j][4 * g + e] + b[g][e] + rs[e] : 0.f;
+                        float x = fv ? acc.v[i][j][4 * g + e] + b[g][e] + rs[g][e] : 0.f;
                         acc.v[i][j][4 * g + e] = x;
                         s[j] += x;
                     }
@@ -223,18 +275,13 @@ struct EpiResidualLNT {
             }
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
-                const long long row = acc.q(j, lane);
-                if (row >= rows) continue;
-                float* op = out + row * ld + f0;
+                f32x4 v[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (!FULL && f0 + FOFF(i, g) >= nout) continue;
-                    f32x4 v;
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        v[e] = (acc.v[i][j][4 * g + e] - mean[j]) * rstd[j] * ga[g][e] + be[g][e];
-                    *reinterpret_cast<f32x4*>(op + FOFF(i, g)) = v;
-                }
+                        v[g][e] = (acc.v[i][j][4 * g + e] - mean[j]) * rstd[j] * ga[g][e] + be[g][e];
+                tile_store<FULL>(wt, v, out, ld, (long long)acc.q0 + j * 32, rows, acc.p0 + i * 32, nout);
             }
             AMDREC_EPI_FENCE();
         }
@@ -258,6 +305,7 @@ struct EpiL2NormT {
         static_assert(A::WP == 2, "L2-norm epilogue: two feature waves per row");
         const int lane = threadIdx.x & 63;
         const int wp = acc.wp, wq = acc.wq;
+        WaveTile wt(smem, lane);
         const int f0 = acc.p(0, 0, lane);
         const float* bp = bias + f0;
         float s[TQ];
@@ -287,20 +335,16 @@ struct EpiL2NormT {
         row_allreduce<TQ, A::BQ>(s, smem, 0, wp, wq, lane);
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
-            const long long row = acc.q(j, lane);
-            if (row >= rows) continue;
             const float inv = 1.0f / fmaxf(sqrtf(s[j]), eps);
-            float* op = out + row * ldo + f0;
 #pragma unroll
-            for (int i = 0; i < TP; ++i)
+            for (int i = 0; i < TP; ++i) {
+                f32x4 v[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (!FULL && f0 + FOFF(i, g) >= nout) continue;
-                    f32x4 v;
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc.v[i][j][4 * g + e] * inv;
-                    *reinterpret_cast<f32x4*>(op + FOFF(i, g)) = v;
-                }
+                    for (int e = 0; e < 4; ++e) v[g][e] = acc.v[i][j][4 * g + e] * inv;
+                tile_store<FULL>(wt, v, out, ldo, (long long)acc.q0 + j * 32, rows, acc.p0 + i * 32, nout);
+            }
         }
     }
 };

@@ -47,6 +47,38 @@ struct EpiStore {   // plain store of the accumulators (row-major [q][p])
         }
     }
 };
+// store through a wave-private, XOR-swizzled LDS tile so that every global store writes full 128-B lines
+struct EpiStoreLines {
+    static constexpr const char* name = "store_lines";
+    static constexpr double out_bytes_per_elem = 1.0;
+    float* out; long long ld; long long rows;
+    template <class A> __device__ void operator()(A& acc, float* smem) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float* tile = smem + wave * 1024;                       // 32 rows x 32 floats
+        const int r = lane & 31, h = lane >> 5;
+        const int rr = lane >> 3, c = lane & 7;
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc.v[i][j][4 * g + e];
+                    *reinterpret_cast<f32x4*>(tile + r * 32 + (((2 * g + h) ^ (r & 7)) << 2)) = v;
+                }
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row_l = rr + 8 * pass;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row_l * 32 + ((c ^ (row_l & 7)) << 2));
+                    const long long row = acc.q0 + j * 32 + row_l;
+                    if (row < rows) *reinterpret_cast<f32x4*>(out + row * ld + acc.p0 + i * 32 + c * 4) = v;
+                }
+            }
+    }
+};
 struct EpiSink {    // keeps the accumulators alive, writes 1 float per lane
     static constexpr const char* name = "sink";
     static constexpr double out_bytes_per_elem = 0.0;
@@ -96,12 +128,18 @@ int main() {
     CK(hipMemcpy(W, h.data(), 4 << 20, hipMemcpyHostToDevice));
     using S = Shape<2, 2, 4, 2>;
     using S8 = Shape<2, 4, 4, 2, true>;
+    for (int K : {256, 1024}) {   // warm-up pass (the first configuration measured in a process reads ~20 % low)
+        DenseRows lw{W, 256, K, K, 30, 1ll << 30};
+        DenseRows lx{X, rows, K, K, 30, 1ll << 30};
+        run<S>("warm-up", lw, lx, EpiStore{Y, 256, rows}, K, 256, rows);
+    }
     for (int K : {256, 1024}) {
         int N = (K == 256) ? 256 : 256;
         DenseRows lw{W, N, K, K, 30, 1ll << 30};
         DenseRows lx{X, rows, K, K, 30, 1ll << 30};
         NullRows nz{0.5f};
         run<S>("4w 256x128: real loads, store epilogue", lw, lx, EpiStore{Y, N, rows}, K, N, rows);
+        run<S>("4w 256x128: real loads, full-line store epi", lw, lx, EpiStoreLines{Y, N, rows}, K, N, rows);
         run<S>("4w 256x128: real loads, sink epilogue", lw, lx, EpiSink{H}, K, N, rows);
         run<S>("4w 256x128: null Q (rows), real P (weights)", lw, nz, EpiSink{H}, K, N, rows);
         run<S>("4w 256x128: real Q, null P", nz, lx, EpiSink{H}, K, N, rows);
@@ -114,6 +152,7 @@ int main() {
         DenseRows lw{W, N, K, K, 30, 1ll << 30};
         DenseRows lx{X, rows, K, K, 30, 1ll << 30};
         run<S>("4w 256x128: N=1024 real loads, store", lw, lx, EpiStore{Y, N, rows}, K, N, rows);
+        run<S>("4w 256x128: N=1024 real loads, full-line store", lw, lx, EpiStoreLines{Y, N, rows}, K, N, rows);
     }
     return 0;
 }

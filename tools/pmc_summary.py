@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc runs of bench.py into a small JSON (committed under profiles/).
+
+    python tools/pmc_summary.py <dir with *_counter_collection.csv ...> -o profiles/rNN_pmc.json
+
+Units / corrections follow /opt/skills/guides (MI355X_MICROARCH.md §HBM, cdna_hip_programming.md §7):
+FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
+coalesced (16 B/lane) streaming read, so read bytes = 2 x FETCH_SIZE x 1024 for these kernels (all their
+global loads are 16 B/lane); WRITE_SIZE is exact for 16 B/lane stores.  Counters were collected in
+separate passes (FETCH_SIZE and WRITE_SIZE cannot share one).
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import re
+
+
+def short(name):
+    m = re.search(r"gemm_nt_kernel<amdrec::Shape<(\d+), (\d+), (\d+), (\d+)[, \w]*>", name)
+    e = re.search(r"amdrec::(Epi\w+)", name)
+    if m and e:
+        wp, wq, tp, tq = (int(m.group(i)) for i in range(1, 5))
+        epi = {"EpiLinearT": "linear", "EpiResidualLNT": "residual_ln", "EpiCrossT": "cross", "EpiL2NormT": "l2norm",
+               "EpiFilter": "search_filter", "EpiStoreScores": "search_sample"}.get(e.group(1), e.group(1))
+        gather = "_gather" if "EmbConcatRows" in name else ""
+        return f"{epi}{gather}_{32 * wp * tp}x{32 * wq * tq}"
+    return name.split("(")[0].replace("amdrec::", "").replace("void ", "")[:60]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dirs", nargs="+")
+    ap.add_argument("-o", "--out", required=True)
+    a = ap.parse_args()
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(lambda: collections.defaultdict(int))
+    for d in a.dirs:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                launches[k][r["Counter_Name"]] += 1
+    out = {}
+    for k, c in agg.items():
+        e = {}
+        if "FETCH_SIZE" in c:
+            n = launches[k]["FETCH_SIZE"]
+            e["launches"] = n
+            e["read_bytes_per_launch"] = 2.0 * c["FETCH_SIZE"] * 1024 / n
+        if "WRITE_SIZE" in c:
+            n = launches[k]["WRITE_SIZE"]
+            e["write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024 / n
+        if "read_bytes_per_launch" in e and "write_bytes_per_launch" in e:
+            e["hbm_bytes_per_launch"] = e["read_bytes_per_launch"] + e["write_bytes_per_launch"]
+        if "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
+            g = c["GRBM_GUI_ACTIVE"] / 8.0                      # sum over the 8 XCDs
+            e["mfma_busy_frac"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (g * 1024)   # 256 CUs x 4 SIMDs
+            if c.get("SQ_WAVE_CYCLES"):
+                e["wave_wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        if e:
+            out[k] = e
+    with open(a.out, "w") as f:
+        json.dump({"note": "per-launch averages over all launches of the run; see tools/pmc_summary.py for units "
+                           "and the gfx950 FETCH_SIZE x2 correction", "kernels": out}, f, indent=1, sort_keys=True)
+    for k, e in sorted(out.items()):
+        print(k, {kk: (round(v, 3) if isinstance(v, float) and v < 10 else int(v)) for kk, v in e.items()})
+
+
+if __name__ == "__main__":
+    main()
