@@ -75,6 +75,27 @@ def device_corpus(n, dim, device, seed=1234, row0=0, rows=None):
     return out
 
 
+def pmc_traffic(tag):
+    """HBM bytes per launch of the kernel family behind a bench tag, from the committed PMC summary
+    (profiles/rNN_pmc.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command, gfx950 x2 read correction applied - tools/pmc_summary.py).  None if no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None
+    epi, shape = tag.rsplit("_", 1)
+    fam = [v for name, v in k.items() if name in (tag, f"{epi}_gather_{shape}") and "hbm_bytes_per_launch" in v]
+    if not fam:
+        return None
+    n = sum(v["launches"] for v in fam)
+    return {"hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / n),
+            "source": os.path.basename(files[-1])}
+
+
 def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, n_users):
     """The CPU oracle (port of the reference path) timed on this host's cores on a bounded
     sample of the same workload: n_users users against the full 1M corpus."""
@@ -189,8 +210,12 @@ def main():
             name, p = dom
             avg_ms = p["total_ms"] / p["launches"]
             achieved = p["flops"] / p["launches"] / (avg_ms * 1e-3) / 1e12
+            tr = pmc_traffic(name)
             roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
+                        "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                        "traffic_source": tr["source"] if tr else None,
+                        "alg_bytes_per_launch": round(p["bytes"] / p["launches"]),
                         "kernel": name, "launches_per_step": p["launches"] / args.steps,
                         "avg_launch_ms": round(avg_ms, 4),
                         "alg_gflop_per_launch": round(p["flops"] / p["launches"] / 1e9, 3)}
