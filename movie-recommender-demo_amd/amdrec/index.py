@@ -141,10 +141,19 @@ class FAISSIndex:
         if not self._trained:
             self.train(embeddings)                                   # :107-108 (un-normalised input)
         t0 = time.time()
-        x = self._normalize_(self._to_device_f32(embeddings))        # :114-115
-        m = x.shape[0]
+        # fp32 copy of the input straight into index storage, renormalised there (:114-118): the
+        # caller's array is never modified and no second device copy is made
+        if isinstance(embeddings, torch.Tensor):
+            src = embeddings.detach()
+        else:
+            src = torch.from_numpy(np.ascontiguousarray(np.asarray(embeddings), dtype=np.float32))
+        if src.dim() != 2 or src.shape[1] != self.dimension:
+            raise ValueError(f"expected [n, {self.dimension}] embeddings, got {tuple(src.shape)}")
+        m = src.shape[0]
         self._reserve(self._n + m)
-        self._xb[self._n:self._n + m].copy_(x)                       # :118
+        x = self._xb[self._n:self._n + m]
+        x.copy_(src)                                                 # casts + moves to the device
+        self._normalize_(x)
         if ad_ids is None:                                           # :121-122
             new_ids = torch.arange(self._n, self._n + m, dtype=torch.int64, device=self.device)
             if self._host_ids is not None:
