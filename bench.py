@@ -130,6 +130,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=48)
     ap.add_argument("--sweep", action="store_true", help="also print the search-only B sweep (stderr)")
+    ap.add_argument("--ads", type=int, default=N_ADS, help="corpus size (configs[3]: 10000000)")
+    ap.add_argument("--index", choices=["flat", "ivf"], default="flat", help="configs[4]: ivf")
+    ap.add_argument("--nlist", type=int, default=4096, help="IVF lists over the WHOLE corpus (split over the ranks)")
+    ap.add_argument("--nprobe", type=int, default=64, help="IVF probes over the whole corpus (split over the ranks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,15 +160,25 @@ def main():
     from amdrec.pipeline import AdRecommenderInference
     _lib.load()
 
+    n_ads = args.ads
     tt, rk, (tt_sd, rk_sd), dims = build_models(device)
     user, ad, nnum = dims
-    per = (N_ADS + world - 1) // world
-    row0, rows = rank * per, max(0, min(per, N_ADS - rank * per))
-    shard = device_corpus(N_ADS, DIM, device, row0=row0, rows=rows)
-    index = FAISSIndex(DIM, index_type="Flat", device=device)
+    per = (n_ads + world - 1) // world
+    row0, rows = rank * per, max(0, min(per, n_ads - rank * per))
+    shard = device_corpus(n_ads, DIM, device, row0=row0, rows=rows)
+    if args.index == "ivf":
+        # each rank is an independent IVF index over its rows: nlist/world lists, nprobe/world probes per rank
+        index = FAISSIndex(DIM, index_type="IVF", nlist=max(1, args.nlist // world),
+                           nprobe=max(1, args.nprobe // world), device=device)
+    else:
+        index = FAISSIndex(DIM, index_type="Flat", device=device)
     index.add(shard)                                        # renormalises + stores (faiss_retrieval.py:97-127)
+    flat_ref = None
+    if args.index == "ivf":
+        flat_ref = FAISSIndex(DIM, index_type="Flat", device=device)     # for recall@500 vs Flat (stderr)
+        flat_ref.add(shard)
     del shard
-    ad_table = torch.from_numpy(synth.ad_features(ad, N_ADS, seed=99)).to(device)   # replicated (160 MB)
+    ad_table = torch.from_numpy(synth.ad_features(ad, n_ads, seed=99)).to(device)   # replicated (160 MB / 1M)
     rec = AdRecommenderInference(two_tower_model=tt, transformer_ranker=rk, faiss_index=index,
                                  ad_features=ad_table)
     B_global = USERS_PER_GPU * world
@@ -226,7 +240,7 @@ def main():
         search = None
         if sf:
             ms = sf["total_ms"] / sf["launches"]
-            alg_bytes = rows * DIM * 4 + B_global * DIM * 4 + B_global * STAGE1_K * 12
+            alg_bytes = rows * DIM * 4 + B_global * DIM * 4 + B_global * STAGE1_K * 12   # this rank's shard
             search = {"filter_pass_ms": round(ms, 3), "alg_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
                       "hbm_frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "tflops": round(sf["flops"] / sf["launches"] / (ms * 1e-3) / 1e12, 2),
@@ -235,27 +249,63 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             corpus_cpu = index._xb[:index._n].cpu().numpy()
             cpu = cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table.cpu().numpy(), args.cpu_users)
-        line = {"metric": "end-to-end recs/sec (1M ads d=256, top-500->10)", "value": round(value, 1),
+            if n_ads != N_ADS:
+                cpu["sample"] = cpu["sample"].replace("1M ads", f"{n_ads} ads")
+        default_cfg = n_ads == N_ADS and args.index == "flat"
+        line = {"metric": "end-to-end recs/sec (1M ads d=256, top-500->10)" if default_cfg else
+                          f"end-to-end recs/sec ({n_ads} ads d=256, {args.index}, top-500->10)", "value": round(value, 1),
                 "unit": "recs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "configs[2]: 1M synthetic ads d=256, UserTower batch=512/GPU, "
-                                       "exact IP top-500, TransformerRanker(256,8 heads,3 layers) on 500 cands, top-10",
-                           "n_ads": N_ADS, "dim": DIM, "users_per_step": B_global, "stage1_k": STAGE1_K,
+                "config": {"workload": ("configs[2]: 1M synthetic ads d=256, UserTower batch=512/GPU, "
+                                        "exact IP top-500, TransformerRanker(256,8 heads,3 layers) on 500 cands, top-10")
+                           if default_cfg else f"{n_ads} ads, index={args.index}"
+                           + (f" nlist={args.nlist} nprobe={args.nprobe}" if args.index == "ivf" else ""),
+                           "n_ads": n_ads, "dim": DIM, "users_per_step": B_global, "stage1_k": STAGE1_K,
                            "top_k": TOP_K, "corpus_rows_per_gpu": rows,
                            "parallelism": f"corpus row-sharded x{world}, ranker data-parallel over users"},
                 "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "search": search}
         print(json.dumps(line), flush=True)
+    if flat_ref is not None and world == 1 and rank == 0:
+        emb = tt.get_user_embeddings(uc, un)
+        a, _ = index.search_device(emb, STAGE1_K)
+        b, _ = flat_ref.search_device(emb, STAGE1_K)
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        rec_at_k = float(np.mean([len(set(x) & set(y)) / STAGE1_K for x, y in zip(a, b)]))
+        print(json.dumps({"ivf_recall_at_500_vs_flat": round(rec_at_k, 4), "nlist": index.nlist,
+                          "nprobe": index.nprobe, "n_ads": n_ads}), file=sys.stderr, flush=True)
     if args.sweep and rank == 0 and world == 1:
         search_sweep(index, device)
+        latency_sweep(rec, uc, un, device)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def latency_sweep(rec, uc, un, device, reps=30):
+    """End-to-end latency of one recommend_device call (device-resident inputs) by batch size; B = 1 is what
+    the reference's recommend_ads serves (it claims "<100 ms", README.md:193)."""
+    rows = []
+    for B in (1, 8, 64, 512):
+        for _ in range(3):
+            rec.recommend_device(uc[:B], un[:B], TOP_K, STAGE1_K)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            rec.recommend_device(uc[:B], un[:B], TOP_K, STAGE1_K)
+        e1.record()
+        torch.cuda.synchronize(device)
+        ms = e0.elapsed_time(e1) / reps
+        rows.append({"B": B, "ms_per_call": round(ms, 3), "recs_per_s": round(B / ms * 1e3, 1)})
+    print(json.dumps({"e2e_latency_by_batch": rows}), file=sys.stderr, flush=True)
+
+
 def search_sweep(index, device, reps=20):
     """Search-only sweep over queries per corpus pass: achieved algorithmic HBM GB/s
     and fp32 TFLOP/s of the whole search call (sample + threshold + filter + finalize)."""
+    if index.index_type != "Flat":
+        return
     n = index._n
     g = torch.Generator(device=device)
     g.manual_seed(5)
@@ -279,7 +329,7 @@ def search_sweep(index, device, reps=20):
         rows.append({"B": B, "ms": round(ms, 4), "qps": round(B / ms * 1e3, 1),
                      "alg_GBps": round(alg_bytes / ms / 1e6, 1), "hbm_frac": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                      "tflops": round(flops / ms / 1e9, 2), "fp32_frac": round(flops / ms / 1e9 / FP32_PEAK_TFLOPS, 4)})
-    print(json.dumps({"search_sweep_1M_k500": rows}), file=sys.stderr, flush=True)
+    print(json.dumps({f"search_sweep_{n}_k500": rows}), file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":

@@ -133,6 +133,15 @@ int main() {
         DenseRows lx{X, rows, K, K, 30, 1ll << 30};
         run<S>("warm-up", lw, lx, EpiStore{Y, 256, rows}, K, 256, rows);
     }
+    for (int rep = 0; rep < 2; ++rep)
+        for (int K : {256, 1024})
+            for (int pad : {0, 8, 32, 96}) {      // leading dimension K + pad floats (power-of-two stride vs padded)
+                char lab[64];
+                snprintf(lab, sizeof(lab), "ld = K + %d: real loads, sink", pad);
+                DenseRows lw{W, 256, K + pad, K, 30, 1ll << 30};
+                DenseRows lx{X, rows * 1024 / (K + pad) < rows ? rows * 1024 / (K + pad) : rows, K + pad, K, 30, 1ll << 30};
+                run<S>(lab, lw, lx, EpiSink{H}, K, 256, rows * 1024 / (K + pad) < rows ? rows * 1024 / (K + pad) : rows);
+            }
     for (int K : {256, 1024}) {
         int N = (K == 256) ? 256 : 256;
         DenseRows lw{W, N, K, K, 30, 1ll << 30};
