@@ -297,7 +297,19 @@ def latency_sweep(rec, uc, un, device, reps=30):
         e1.record()
         torch.cuda.synchronize(device)
         ms = e0.elapsed_time(e1) / reps
-        rows.append({"B": B, "ms_per_call": round(ms, 3), "recs_per_s": round(B / ms * 1e3, 1)})
+        row = {"B": B, "ms_per_call": round(ms, 3), "recs_per_s": round(B / ms * 1e3, 1)}
+        if B <= 64:                                  # hipGraph replay of the same call
+            g = rec.capture(B, TOP_K, STAGE1_K)
+            for _ in range(3):
+                g(uc[:B], un[:B])
+            torch.cuda.synchronize(device)
+            e0.record()
+            for _ in range(reps):
+                g(uc[:B], un[:B])
+            e1.record()
+            torch.cuda.synchronize(device)
+            row["ms_per_call_hipgraph"] = round(e0.elapsed_time(e1) / reps, 3)
+        rows.append(row)
     print(json.dumps({"e2e_latency_by_batch": rows}), file=sys.stderr, flush=True)
 
 

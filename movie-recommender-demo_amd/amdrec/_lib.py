@@ -113,13 +113,23 @@ def profile_report():
 
 
 class Workspace:
-    """Grow-only per-device scratch buffer handed to the C ABI (caller-owned workspace)."""
+    """Grow-only per-device scratch buffer handed to the C ABI (caller-owned workspace).
+
+    Kernels launched on one stream use it one after the other, so a single buffer per device is enough
+    for eager calls.  A captured HIP graph bakes the buffer's address into its kernel nodes, so it must
+    never share (or outlive) a buffer that may be re-allocated: ``private()`` installs a separate,
+    pre-sized arena for the duration of a capture and the graph owner keeps it alive."""
 
     def __init__(self):
         self._buf = {}
+        self._override = None
 
     def get(self, nbytes, device):
+        if self._override is not None:
+            return self._override.get(nbytes, device)
         key = torch.device(device)
+        if key.index is None and key.type == "cuda":
+            key = torch.device("cuda", torch.cuda.current_device())
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = None
@@ -128,6 +138,44 @@ class Workspace:
             assert buf.data_ptr() % 256 == 0
             self._buf[key] = buf
         return buf
+
+    def private(self, arena: "FixedArena"):
+        ws = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev, ws._override = ws._override, arena
+                return arena
+
+            def __exit__(self_, *exc):
+                ws._override = self_.prev
+                return False
+        return _Ctx()
+
+
+class FixedArena:
+    """A workspace of fixed size that refuses to grow (for graph capture)."""
+
+    def __init__(self, nbytes, device):
+        self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        self.high_water = 0
+
+    def get(self, nbytes, device):
+        self.high_water = max(self.high_water, int(nbytes))
+        if nbytes > self.buf.numel():
+            raise AmdrecError(f"graph workspace too small: need {nbytes} bytes, have {self.buf.numel()}")
+        return self.buf
+
+
+class MeasuringArena:
+    """Records the largest request while delegating to the shared workspace (sizing pass)."""
+
+    def __init__(self, inner):
+        self.inner, self.high_water = inner, 0
+
+    def get(self, nbytes, device):
+        self.high_water = max(self.high_water, int(nbytes))
+        return self.inner.get(nbytes, device)
 
 
 WORKSPACE = Workspace()

@@ -140,7 +140,7 @@ struct Shape {
     static constexpr int STAGE_FLOATS = (BP + BQ) * BK;
     static constexpr size_t LDS_BYTES = (DBUF ? 2ull : 1ull) * STAGE_FLOATS * sizeof(float);
     static constexpr int ROWS_PER_PASS = NT / 8;     // 8 x 16-byte chunks per 128-byte row segment
-    static_assert(BP % ROWS_PER_PASS == 0 && BQ % ROWS_PER_PASS == 0, "tile rows must fill whole staging passes");
+    static_assert(BP % ROWS_PER_PASS == 0, "P tile rows must fill whole staging passes");
 };
 
 // Accumulator tile set of one wave and where it sits in the output.
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
     // staging assignment: thread handles 16-B chunk (tid&7) of rows (tid>>3) + ROWS_PER_PASS*u
     const int srow = tid >> 3, schunk = tid & 7;
     constexpr int RPP = S::ROWS_PER_PASS;
-    constexpr int NP = BP / RPP, NQ = BQ / RPP;
+    constexpr int NP = BP / RPP, NQ = (BQ + RPP - 1) / RPP;
+    constexpr bool QPART = BQ % RPP != 0;            // Q tile shorter than one staging pass (small-M shapes)
     f32x4 rp[NP], rq[NQ];
 
     auto stage_load = [&](int kt) {
@@ -186,7 +187,9 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
 #pragma unroll
         for (int u = 0; u < NP; ++u) rp[u] = pv ? lp.load(prow0 + srow + RPP * u, k) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) rq[u] = qv ? lq.load(qrow0 + srow + RPP * u, k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NQ; ++u)
+            if (!QPART || srow + RPP * u < BQ)
+                rq[u] = qv ? lq.load(qrow0 + srow + RPP * u, k) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto stage_store = [&](int buf) {
         float* sp = smem + buf * S::STAGE_FLOATS;
@@ -194,7 +197,8 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
 #pragma unroll
         for (int u = 0; u < NP; ++u) *reinterpret_cast<f32x4*>(sp + lds_slot(srow + RPP * u, schunk)) = rp[u];
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) *reinterpret_cast<f32x4*>(sq + lds_slot(srow + RPP * u, schunk)) = rq[u];
+        for (int u = 0; u < NQ; ++u)
+            if (!QPART || srow + RPP * u < BQ) *reinterpret_cast<f32x4*>(sq + lds_slot(srow + RPP * u, schunk)) = rq[u];
     };
 
     Acc<TP, TQ, S::WP, S::WQ> acc;
@@ -257,10 +261,13 @@ template <class S, bool P_IS_SMALL, class LoadP, class LoadQ, class Epi>
 inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, int K, long long p_rows,
                               long long q_rows, hipStream_t stream, int k_alg = 0) {
     auto kern = gemm_nt_kernel<S, P_IS_SMALL, LoadP, LoadQ, Epi>;
+    // dynamic LDS = the larger of the staging tiles and what the epilogue carves out of the same array
+    constexpr size_t lds_bytes = S::LDS_BYTES > Epi::lds_bytes(S::NT / 64) ? S::LDS_BYTES : Epi::lds_bytes(S::NT / 64);
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -276,7 +283,7 @@ inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, 
     ProfScope prof(tag, 2.0 * (double)p_rows * (double)q_rows * ka,
                    4.0 * ((double)p_rows * ka + (double)q_rows * ka + Epi::out_bytes_per_elem * (double)p_rows * (double)q_rows),
                    stream);
-    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(S::NT), S::LDS_BYTES, stream, lp, lq, epi, ksteps, tm);
+    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(S::NT), lds_bytes, stream, lp, lq, epi, ksteps, tm);
     return hipGetLastError();
 }
 

@@ -16,6 +16,12 @@ namespace amdrec {
 
 using ShapeWide = Shape<2, 2, 4, 2>;    // 256 features x 128 rows per workgroup (4 waves)
 using ShapeNarrow = Shape<2, 2, 1, 4>;  //  64 features x 256 rows per workgroup
+// Small batches (a single request = 500 candidate rows): with the shapes above a layer occupies 4 CUs and
+// every wave runs a 128-MFMA chain per K-step (~40 us per 256x256 layer).  These shapes give each of 8
+// waves ONE 32x32 tile: 16 workgroups for 500 rows and a 16-MFMA chain per K-step.
+using ShapeSmall = Shape<8, 1, 1, 1>;        // 256 features x 32 rows, 8 waves
+using ShapeSmallNarrow = Shape<2, 4, 1, 1>;  //  64 features x 128 rows, 8 waves
+constexpr long long SMALL_ROWS = 8192;       // rows <= this use the small shapes
 
 // Epilogue data movement.  In the accumulator a lane owns row q(j) and, per tile i and register group g,
 // the 4 consecutive features 32*i + 8*g + 4*(lane>>5) + {0..3}: a direct store instruction would cover
@@ -28,6 +34,7 @@ using ShapeNarrow = Shape<2, 2, 1, 4>;  //  64 features x 256 rows per workgroup
 #define FOFF(i, g) ((i) * 32 + (g) * 8)
 constexpr int EPI_TILE_FLOATS = 1024;        // 32 rows x 32 floats per wave
 constexpr int EPI_TILE_BASE = 1024;          // floats reserved below the tiles for row reductions
+constexpr size_t epi_lds_bytes(int nwaves) { return (size_t)(EPI_TILE_BASE + nwaves * EPI_TILE_FLOATS) * sizeof(float); }
 
 struct WaveTile {
     float* t;
@@ -87,6 +94,7 @@ template <bool FULL>
 struct EpiLinearT {
     static constexpr const char* name = "linear";
     static constexpr double out_bytes_per_elem = 1.0;
+    static constexpr size_t lds_bytes(int nwaves) { return epi_lds_bytes(nwaves); }
     const float* bias;
     float* out;
     long long ldo;
@@ -128,6 +136,7 @@ template <bool FULL>
 struct EpiCrossT {
     static constexpr const char* name = "cross";
     static constexpr double out_bytes_per_elem = 1.0;
+    static constexpr size_t lds_bytes(int nwaves) { return epi_lds_bytes(nwaves); }
     const float* bias;
     const float* x0;
     const float* xl;
@@ -169,13 +178,13 @@ struct EpiCrossT {
 // Row statistics over the nout (<= 256) features of a row.  The workgroup is one P tile wide
 // (ShapeWide: 2 waves x 128 features), so: in-lane sum over the lane's 64 values, exchange
 // with lane^32 (other row-group half of the same tiles), exchange between the 2 feature
-// waves through LDS.  `red` is [2 phases][2 wp][BQ rows] (<= EPI_TILE_BASE floats).
-template <int TQ, int BQ>
+// waves through LDS.  `red` is [2 phases][WP][BQ rows] (<= EPI_TILE_BASE floats).
+template <int TQ, int BQ, int WP>
 __device__ __forceinline__ void row_allreduce(float (&part)[TQ], float* red, int phase, int wp, int wq, int lane) {
-    static_assert(4 * BQ <= EPI_TILE_BASE, "reduction scratch overlaps the epilogue tiles");
+    static_assert(2 * WP * BQ <= EPI_TILE_BASE, "reduction scratch overlaps the epilogue tiles");
 #pragma unroll
     for (int j = 0; j < TQ; ++j) part[j] += __shfl_xor(part[j], 32, 64);
-    float* r = red + phase * 2 * BQ;
+    float* r = red + phase * WP * BQ;
     if (lane < 32) {
 #pragma unroll
         for (int j = 0; j < TQ; ++j) r[wp * BQ + wq * TQ * 32 + j * 32 + lane] = part[j];
@@ -183,8 +192,11 @@ __device__ __forceinline__ void row_allreduce(float (&part)[TQ], float* red, int
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TQ; ++j) {
-        int idx = wq * TQ * 32 + j * 32 + (lane & 31);
-        part[j] = r[idx] + r[BQ + idx];
+        const int idx = wq * TQ * 32 + j * 32 + (lane & 31);
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < WP; ++w) a += r[w * BQ + idx];     // fixed order: deterministic
+        part[j] = a;
     }
 }
 
@@ -193,6 +205,7 @@ template <bool FULL>
 struct EpiResidualLNT {
     static constexpr const char* name = "residual_ln";
     static constexpr double out_bytes_per_elem = 1.0;
+    static constexpr size_t lds_bytes(int nwaves) { return epi_lds_bytes(nwaves); }
     const float* bias;
     const float* resid;
     const float* gamma;
@@ -205,7 +218,7 @@ struct EpiResidualLNT {
     template <class A>
     __device__ void operator()(A& acc, float* smem) const {
         constexpr int TP = A::TP, TQ = A::TQ;
-        static_assert(A::WP == 2, "LayerNorm epilogue: two feature waves per row");
+        static_assert(A::WP * TP * 32 == 256, "LayerNorm epilogue: the workgroup spans one 256-feature P tile");
         const int lane = threadIdx.x & 63;
         const int wp = acc.wp, wq = acc.wq;
         WaveTile wt(smem, lane);
@@ -238,7 +251,7 @@ struct EpiResidualLNT {
             }
             AMDREC_EPI_FENCE();
         }
-        row_allreduce<TQ, A::BQ>(s, smem, 0, wp, wq, lane);
+        row_allreduce<TQ, A::BQ, A::WP>(s, smem, 0, wp, wq, lane);
         const float inv_n = 1.0f / (float)nout;
         float mean[TQ], q2[TQ];
 #pragma unroll
@@ -258,7 +271,7 @@ struct EpiResidualLNT {
                 }
             q2[j] = a;
         }
-        row_allreduce<TQ, A::BQ>(q2, smem, 1, wp, wq, lane);
+        row_allreduce<TQ, A::BQ, A::WP>(q2, smem, 1, wp, wq, lane);
         float rstd[TQ];
 #pragma unroll
         for (int j = 0; j < TQ; ++j) rstd[j] = 1.0f / sqrtf(q2[j] * inv_n + eps);
@@ -293,6 +306,7 @@ template <bool FULL>
 struct EpiL2NormT {
     static constexpr const char* name = "l2norm";
     static constexpr double out_bytes_per_elem = 1.0;
+    static constexpr size_t lds_bytes(int nwaves) { return epi_lds_bytes(nwaves); }
     const float* bias;
     float* out;
     long long ldo;
@@ -302,7 +316,7 @@ struct EpiL2NormT {
     template <class A>
     __device__ void operator()(A& acc, float* smem) const {
         constexpr int TP = A::TP, TQ = A::TQ;
-        static_assert(A::WP == 2, "L2-norm epilogue: two feature waves per row");
+        static_assert(A::WP * TP * 32 == 256, "L2-norm epilogue: the workgroup spans one 256-feature P tile");
         const int lane = threadIdx.x & 63;
         const int wp = acc.wp, wq = acc.wq;
         WaveTile wt(smem, lane);
@@ -332,7 +346,7 @@ struct EpiL2NormT {
                 }
             AMDREC_EPI_FENCE();
         }
-        row_allreduce<TQ, A::BQ>(s, smem, 0, wp, wq, lane);
+        row_allreduce<TQ, A::BQ, A::WP>(s, smem, 0, wp, wq, lane);
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
             const float inv = 1.0f / fmaxf(sqrtf(s[j]), eps);
@@ -383,23 +397,34 @@ static inline DenseRows dense(const float* p, long long rows, long long ld, int 
 
 // y = epilogue(x W^T): dispatch on the output width; FULL = the width fills whole P tiles, so the
 // epilogue needs no feature-bound checks (true for every layer of the default architecture).
+template <class SW, class SN, bool ALLOW_NARROW, template <bool> class EpiT, class LoadQ, class... EpiArgs>
+static hipError_t linear_shapes(const float* W, int ldw, int nout, const LoadQ& lq, long long rows, hipStream_t st,
+                                int k_alg, EpiArgs... ea) {
+    DenseRows lp = dense(W, nout, ldw, ldw);
+    if constexpr (ALLOW_NARROW) {
+        if (nout <= 64) {
+            if (nout == SN::BP) return launch_gemm<SN, true>(lp, lq, EpiT<true>{ea...}, ldw, nout, rows, st, k_alg);
+            return launch_gemm<SN, true>(lp, lq, EpiT<false>{ea...}, ldw, nout, rows, st, k_alg);
+        }
+    }
+    if (nout % SW::BP == 0) return launch_gemm<SW, true>(lp, lq, EpiT<true>{ea...}, ldw, nout, rows, st, k_alg);
+    return launch_gemm<SW, true>(lp, lq, EpiT<false>{ea...}, ldw, nout, rows, st, k_alg);
+}
+// narrow outputs (<= 64 features) may use the 64-feature shapes
 template <template <bool> class EpiT, class LoadQ, class... EpiArgs>
 static hipError_t linear(const float* W, int ldw, int nout, const LoadQ& lq, long long rows, hipStream_t st,
                          int k_alg, EpiArgs... ea) {
-    DenseRows lp = dense(W, nout, ldw, ldw);
-    if (nout <= 64) {
-        if (nout == ShapeNarrow::BP) return launch_gemm<ShapeNarrow, true>(lp, lq, EpiT<true>{ea...}, ldw, nout, rows, st, k_alg);
-        return launch_gemm<ShapeNarrow, true>(lp, lq, EpiT<false>{ea...}, ldw, nout, rows, st, k_alg);
-    }
-    if (nout % ShapeWide::BP == 0) return launch_gemm<ShapeWide, true>(lp, lq, EpiT<true>{ea...}, ldw, nout, rows, st, k_alg);
-    return launch_gemm<ShapeWide, true>(lp, lq, EpiT<false>{ea...}, ldw, nout, rows, st, k_alg);
+    if (rows <= SMALL_ROWS)
+        return linear_shapes<ShapeSmall, ShapeSmallNarrow, true, EpiT>(W, ldw, nout, lq, rows, st, k_alg, ea...);
+    return linear_shapes<ShapeWide, ShapeNarrow, true, EpiT>(W, ldw, nout, lq, rows, st, k_alg, ea...);
 }
+// epilogues that need a whole 256-feature row in one workgroup (LayerNorm, L2 norm)
 template <template <bool> class EpiT, class LoadQ, class... EpiArgs>
 static hipError_t linear_wide(const float* W, int ldw, int nout, const LoadQ& lq, long long rows, hipStream_t st,
                               int k_alg, EpiArgs... ea) {
-    DenseRows lp = dense(W, nout, ldw, ldw);
-    if (nout % ShapeWide::BP == 0) return launch_gemm<ShapeWide, true>(lp, lq, EpiT<true>{ea...}, ldw, nout, rows, st, k_alg);
-    return launch_gemm<ShapeWide, true>(lp, lq, EpiT<false>{ea...}, ldw, nout, rows, st, k_alg);
+    if (rows <= SMALL_ROWS)
+        return linear_shapes<ShapeSmall, ShapeSmallNarrow, false, EpiT>(W, ldw, nout, lq, rows, st, k_alg, ea...);
+    return linear_shapes<ShapeWide, ShapeNarrow, false, EpiT>(W, ldw, nout, lq, rows, st, k_alg, ea...);
 }
 
 static inline int ilog2(int v) {

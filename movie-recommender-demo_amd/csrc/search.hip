@@ -31,6 +31,7 @@ constexpr int SAMPLE_G = 256;      // rows per sample block (== BP of every sear
 struct EpiStoreScores {
     static constexpr const char* name = "search_sample";
     static constexpr double out_bytes_per_elem = 1.0;
+    static constexpr size_t lds_bytes(int) { return 0; }
     float* out;          // [nq][ld]
     long long ld;
     int nq;
@@ -65,6 +66,7 @@ struct EpiStoreScores {
 struct EpiFilter {
     static constexpr const char* name = "search_filter";
     static constexpr double out_bytes_per_elem = 0.0;
+    static constexpr size_t lds_bytes(int) { return 0; }
     const float* tau;            // [nq]
     unsigned long long* cand;    // [nq][cap]
     int* cnt;                    // [nq]

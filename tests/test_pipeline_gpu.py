@@ -102,6 +102,31 @@ def test_reference_api_schema_and_preprocessing():
     assert single["ad_ids"] == rs[3]["ad_ids"]
 
 
+def test_hipgraph_replay_equals_eager():
+    rec, _, (user, ad, nnum) = _setup(9000, 1.0 / 16)
+    for B in (1, 5):
+        g = rec.capture(B, top_k=10, stage1_k=500)
+        for seed in range(1, 9):
+            uc, un = synth.user_batch(user, nnum, B, seed=seed)
+            uc, un = torch.from_numpy(uc).cuda(), torch.from_numpy(un).cuda()
+            a = rec.recommend_device(uc, un, 10, 500)
+            a = {k: v.clone() for k, v in a.items() if isinstance(v, torch.Tensor)}
+            b = g(uc, un)
+            torch.cuda.synchronize()
+            for k in ("ad_ids", "scores", "candidate_ids", "candidate_scores"):
+                assert torch.equal(a[k], b[k]), (B, seed, k)
+    with pytest.raises(ValueError):
+        g(uc[:1].repeat(7, 1), un[:1].repeat(7, 1))
+    # a later, larger eager call re-allocates the shared workspace; the graph owns a private one
+    big_uc, big_un = synth.user_batch(user, nnum, 64, seed=99)
+    rec.recommend_device(torch.from_numpy(big_uc).cuda(), torch.from_numpy(big_un).cuda(), 10, 500)
+    a = rec.recommend_device(uc, un, 10, 500)
+    a = {k: v.clone() for k, v in a.items() if isinstance(v, torch.Tensor)}
+    b = g(uc, un)
+    torch.cuda.synchronize()
+    assert torch.equal(a["ad_ids"], b["ad_ids"]) and torch.equal(a["candidate_scores"], b["candidate_scores"])
+
+
 def test_index_save_load_roundtrip(tmp_path):
     rec, (tt_sd, rk_sd, oidx, ad_table), (user, ad, nnum) = _setup(2000, 1.0 / 16)
     from amdrec.index import FAISSIndex

@@ -25,6 +25,7 @@ struct NullRows {   // no memory traffic: operand values come from registers
 struct EpiStore {   // plain store of the accumulators (row-major [q][p])
     static constexpr const char* name = "store";
     static constexpr double out_bytes_per_elem = 1.0;
+    static constexpr size_t lds_bytes(int) { return 0; }
     float* out; long long ld; long long rows;
     template <class A> __device__ void operator()(A& acc, float*) const {
         constexpr int TP = A::TP, TQ = A::TQ;
@@ -51,6 +52,7 @@ struct EpiStore {   // plain store of the accumulators (row-major [q][p])
 struct EpiStoreLines {
     static constexpr const char* name = "store_lines";
     static constexpr double out_bytes_per_elem = 1.0;
+    static constexpr size_t lds_bytes(int nwaves) { return (size_t)nwaves * 4096; }
     float* out; long long ld; long long rows;
     template <class A> __device__ void operator()(A& acc, float* smem) const {
         constexpr int TP = A::TP, TQ = A::TQ;
@@ -82,6 +84,7 @@ struct EpiStoreLines {
 struct EpiSink {    // keeps the accumulators alive, writes 1 float per lane
     static constexpr const char* name = "sink";
     static constexpr double out_bytes_per_elem = 0.0;
+    static constexpr size_t lds_bytes(int) { return 0; }
     float* out;
     template <class A> __device__ void operator()(A& acc, float*) const {
         float s = 0.f;
