@@ -59,6 +59,16 @@ int amdrec_ivf_scan(const float* lists, int64_t ld, int dim, const int64_t* row_
                     const int64_t* list_off, const float* queries, int64_t nq, int64_t ld_queries,
                     const int64_t* probes, const int64_t* pool_base, int nprobe, uint64_t* pool_keys,
                     int64_t pool_ld, int64_t pos_offset, void* stream);
+/* Batched form of step 3: the (query, probe) pairs sorted by list (pair_query / pair_probe, group_off
+ * [nlist+1]); qtile_prefix[nlist+1] = prefix sum of ceil(group size / 64); qtile_bound >= qtile_prefix[nlist]
+ * (a host-side upper bound, e.g. pairs/64 + nlist, <= 65535).  Every list is read once per 64-query group
+ * by an fp32-MFMA GEMM tile instead of once per probing query.  Same pool layout and keys as amdrec_ivf_scan. */
+int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, const int64_t* row_pos,
+                            const int64_t* list_off, int nlist, int64_t max_list_rows, const float* queries,
+                            int64_t ld_queries, const int64_t* group_off, const int64_t* qtile_prefix,
+                            int64_t qtile_bound, const int64_t* pair_query, const int64_t* pair_probe,
+                            const int64_t* pool_base, int nprobe, uint64_t* pool_keys, int64_t pool_ld,
+                            int64_t pos_offset, void* stream);
 int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count /*[nq]*/,
                       int64_t nq, int k, float* out_scores /*[nq][k]*/, int64_t* out_pos /*[nq][k]*/,
                       void* stream);

@@ -23,6 +23,8 @@ NITER = 10
 MAX_POINTS_PER_CENTROID = 256
 SEED = 1234
 POOL_BYTES = 2 << 30           # candidate-pool workspace per query chunk
+GROUPED_MIN_QUERIES = 16       # batches at least this large scan list-major (every list read once per 64 queries)
+QTILE = 64                     # queries per grouped-scan tile (ShapeIvf::BP)
 
 
 def _normalize(x):
@@ -113,13 +115,34 @@ class IVFState:
         n_pool = plen.sum(1).contiguous()
         pool_ld = max(1, nprobe * max_len)
         chunk = max(1, min(nq, 65535, POOL_BYTES // (pool_ld * 8)))
+        grouped = nq >= GROUPED_MIN_QUERIES
+        if grouped:                                   # one launch needs pairs/64 + nlist <= 65535 query tiles
+            chunk = max(1, min(chunk, ((65535 - self.nlist) * QTILE) // nprobe))
         ws = _lib.WORKSPACE.get(chunk * pool_ld * 8, self.device)
         st = _lib.stream_ptr(self.device)
         for s in range(0, nq, chunk):
             m = min(chunk, nq - s)
-            _lib.check(lib.amdrec_ivf_scan(_lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off),
-                                           _lib.ptr(q[s:]), m, q.stride(0), _lib.ptr(probes[s:]), _lib.ptr(base[s:]),
-                                           nprobe, _lib.ptr(ws), pool_ld, pos_offset, st))
+            if grouped:
+                # sort this chunk's (query, probe) pairs by list: integer plumbing on [m * nprobe] elements
+                pl = probes[s:s + m].reshape(-1)
+                ls = torch.where(pl < 0, torch.full_like(pl, self.nlist), pl)
+                order = torch.argsort(ls, stable=True)
+                pair_q = (order // nprobe).contiguous()
+                pair_p = (order % nprobe).contiguous()
+                gcount = torch.bincount(ls, minlength=self.nlist + 1)[:self.nlist]
+                goff = torch.zeros(self.nlist + 1, dtype=torch.int64, device=self.device)
+                goff[1:] = torch.cumsum(gcount, 0)
+                qtp = torch.zeros(self.nlist + 1, dtype=torch.int64, device=self.device)
+                qtp[1:] = torch.cumsum((gcount + QTILE - 1) // QTILE, 0)
+                bound = (m * nprobe) // QTILE + self.nlist
+                _lib.check(lib.amdrec_ivf_scan_grouped(
+                    _lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off), self.nlist, max_len,
+                    _lib.ptr(q[s:]), q.stride(0), _lib.ptr(goff), _lib.ptr(qtp), bound, _lib.ptr(pair_q),
+                    _lib.ptr(pair_p), _lib.ptr(base[s:]), nprobe, _lib.ptr(ws), pool_ld, pos_offset, st))
+            else:
+                _lib.check(lib.amdrec_ivf_scan(_lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off),
+                                               _lib.ptr(q[s:]), m, q.stride(0), _lib.ptr(probes[s:]),
+                                               _lib.ptr(base[s:]), nprobe, _lib.ptr(ws), pool_ld, pos_offset, st))
             _lib.check(lib.amdrec_ivf_select(_lib.ptr(ws), pool_ld, _lib.ptr(n_pool[s:]), m, k,
                                              _lib.ptr(out_scores[s:]), _lib.ptr(out_pos[s:]), st))
 

@@ -158,18 +158,11 @@ struct Acc {
     __device__ __forceinline__ int q(int tq, int lane) const { return q0 + tq * 32 + (lane & 31); }
 };
 
-// The mainloop.  P_IS_SMALL: which operand the TileMap's "small" index addresses.
-template <class S, bool P_IS_SMALL, class LoadP, class LoadQ, class Epi>
-__global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(LoadP lp, LoadQ lq, Epi epi, int ksteps, TileMap tm) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// The mainloop for one workgroup: output tile with first P row `prow0` and first Q row `qrow0`.
+template <class S, class LoadP, class LoadQ, class Epi>
+__device__ __forceinline__ void gemm_block(const LoadP& lp, const LoadQ& lq, const Epi& epi, int ksteps,
+                                           long long prow0, long long qrow0, float* smem) {
     constexpr int TP = S::TP, TQ = S::TQ, BP = S::BP, BQ = S::BQ;
-    int small, big;
-    if (!tm.get(blockIdx.x, small, big)) return;
-    const int tile_p = P_IS_SMALL ? small : big;
-    const int tile_q = P_IS_SMALL ? big : small;
-    const long long prow0 = (long long)tile_p * BP;
-    const long long qrow0 = (long long)tile_q * BQ;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wp = wave / S::WQ, wq = wave % S::WQ;
@@ -254,6 +247,17 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(LoadP lp, LoadQ lq, E
         }
     }
     epi(acc, smem);
+}
+
+// Regular grid: P_IS_SMALL says which operand the TileMap's "small" index addresses.
+template <class S, bool P_IS_SMALL, class LoadP, class LoadQ, class Epi>
+__global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(LoadP lp, LoadQ lq, Epi epi, int ksteps, TileMap tm) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int small, big;
+    if (!tm.get(blockIdx.x, small, big)) return;
+    const int tile_p = P_IS_SMALL ? small : big;
+    const int tile_q = P_IS_SMALL ? big : small;
+    gemm_block<S>(lp, lq, epi, ksteps, (long long)tile_p * S::BP, (long long)tile_q * S::BQ, smem);
 }
 
 // k_alg: the un-padded K (for the algorithmic FLOP/byte count of the profiling hook only)
