@@ -1,0 +1,112 @@
+"""CPU tests of the product's HOST-side logic (no kernels): weight packing (BatchNorm fold, K padding,
+table stacking, positional-row fold, W_o.W_v pre-multiplication, cross transpose), the preprocessor and the
+synthetic-data generator.  The packed weights are evaluated with plain numpy and compared with the oracle."""
+import ctypes
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from amdrec import prep, synth, weights
+from amdrec.pipeline import Preprocessor
+from tests import cases
+
+
+def _arr(pk, ptr, shape, dtype=np.float32):
+    """Find the packed (CPU) tensor behind a struct pointer."""
+    for t in pk._keep:
+        if t.data_ptr() == ptr:
+            return t.numpy().reshape(shape)
+    raise KeyError(ptr)
+
+
+def test_tower_packing_folds_batchnorm_exactly():
+    user, ad, nnum, sd, _ = cases.two_tower_case("ragged")
+    p, pk = weights.pack_tower(sd, "user_tower", list(user), nnum, "cpu")
+    assert (p.n_feat, p.emb_dim, p.n_num, p.n_layers) == (6, 16, 13, 3)
+    assert list(p.dims[:4]) == [6 * 16 + 13, 512, 256, 256] and list(p.ldw[:3]) == [128, 512, 256]
+    off = _arr(pk, p.table_off, (6,), np.int32)
+    cards = _arr(pk, p.cards, (6,), np.int32)
+    assert list(cards) == list(user.values()) and list(off) == list(np.cumsum([0] + list(user.values())[:-1]))
+    tables = _arr(pk, p.tables, (sum(user.values()), 16))
+    ucat, unum = synth.user_batch(user, nnum, 37, seed=3)
+    x = np.concatenate([tables[off[f] + ucat[:, f]] for f in range(6)] + [unum], axis=1)
+    for l in range(3):
+        w = _arr(pk, p.w[l], (p.dims[l + 1], p.ldw[l]))
+        b = _arr(pk, p.b[l], (p.dims[l + 1],))
+        assert not w[:, p.dims[l]:].any()                     # K padding is zero
+        x = x @ w[:, :p.dims[l]].T + b
+        if l < 2:
+            x = np.maximum(x, 0)
+    got = oracle.towers.l2_normalize(x.astype(np.float32))
+    assert np.abs(got - oracle.towers.user_tower(sd, ucat, unum)).max() <= cases.EMB_ATOL
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_ranker_packing_matches_oracle(fuse):
+    user, ad, nnum, sd, _ = cases.ranker_case("ragged", "scaled")
+    p, pk, tasks = weights.pack_ranker(sd, list(user), list(ad), nnum, "cpu", fuse_attention=fuse)
+    assert tasks == ["ctr", "engagement", "revenue"] and (p.n_layers, p.n_cross, p.n_tasks) == (3, 3, 3)
+    assert (p.d_model, p.d_ff, p.head_h1, p.head_h2, p.ldw_proj) == (256, 1024, 256, 64, 864)
+    dm = 256
+    ucat, unum = synth.user_batch(user, nnum, 21, seed=4)
+    acat = synth.ad_features(ad, 21, seed=5)
+    feats = oracle.ranker.embed_features(sd, ucat, acat, unum)
+    x = feats @ _arr(pk, p.w_proj, (dm, 864))[:, :845].T + _arr(pk, p.b_proj, (dm,))      # pos[0] folded in
+    for l in range(3):
+        L = p.layers[l]
+        if fuse:
+            assert not L.w_v
+            a = x @ _arr(pk, L.w_o, (dm, dm)).T + _arr(pk, L.b_o, (dm,))
+        else:
+            a = (x @ _arr(pk, L.w_v, (dm, dm)).T + _arr(pk, L.b_v, (dm,))) @ _arr(pk, L.w_o, (dm, dm)).T \
+                + _arr(pk, L.b_o, (dm,))
+        x = oracle.ranker.layer_norm(x + a, _arr(pk, L.ln1_g, (dm,)), _arr(pk, L.ln1_b, (dm,)))
+        h = np.maximum(x @ _arr(pk, L.w_1, (1024, dm)).T + _arr(pk, L.b_1, (1024,)), 0)
+        x = oracle.ranker.layer_norm(x + h @ _arr(pk, L.w_2, (dm, 1024)).T + _arr(pk, L.b_2, (dm,)),
+                                     _arr(pk, L.ln2_g, (dm,)), _arr(pk, L.ln2_b, (dm,)))
+    x0, xl = x, x
+    for c in range(3):
+        xl = x0 * (xl @ _arr(pk, p.cross_wt[c], (dm, dm)).T + _arr(pk, p.cross_b[c], (dm,))) + xl   # stored transposed
+    h1 = np.maximum(xl @ _arr(pk, p.head_w1, (768, dm)).T + _arr(pk, p.head_b1, (768,)), 0)
+    ref = oracle.ranker.forward(sd, ucat, acat, unum)
+    scale = cases.logit_scale(ref)
+    for t, task in enumerate(tasks):
+        h2 = np.maximum(h1[:, 256 * t:256 * (t + 1)] @ _arr(pk, p.head_w2[t], (64, 256)).T
+                        + _arr(pk, p.head_b2[t], (64,)), 0)
+        logit = h2 @ _arr(pk, p.head_w3[t], (64,)) + _arr(pk, p.head_b3[t], (1,))[0]
+        ok, err = cases.logit_close(logit, ref[task], scale=scale)
+        assert ok, (task, err)
+
+
+def test_packing_rejects_unsupported_embedding_dim():
+    user, ad, nnum = synth.demo_dims()
+    sd = synth.two_tower_state(user, ad, nnum, seed=1, embedding_dim=12)
+    with pytest.raises(ValueError):
+        weights.pack_tower(sd, "user_tower", list(user), nnum, "cpu")
+
+
+def test_synthetic_criteo_and_preprocessor(tmp_path):
+    num, cat, labels = prep.synthetic_criteo(4000)
+    assert num.shape == (4000, 13) and len(cat) == 26 and set(np.unique(labels)) <= {0, 1}
+    num2, cat2, _ = prep.synthetic_criteo(4000)
+    assert np.array_equal(num, num2) and all(np.array_equal(cat[c], cat2[c]) for c in cat)   # seeded (seed 42)
+    pp, num_scaled, enc = prep.fit_preprocessor(num, cat)
+    assert num_scaled.dtype == np.float32 and np.abs(num_scaled.mean(axis=0)).max() < 1e-4
+    assert np.abs(num_scaled.std(axis=0) - 1).max() < 1e-3
+    assert "rare" in pp.classes["C1"]                         # 1000 categories over 4000 rows: most are < 10
+    assert pp.feature_dims["C26"] == 10 and enc[:, 25].max() == 9
+    assert all(enc[:, i].max() < pp.feature_dims[f"C{i + 1}"] for i in range(26))
+    # unknown -> 'rare' when the encoder has it, else class 0 (documented deviation from inference.py:180)
+    assert pp.encode("C1", "never-seen") == pp.classes["C1"].index("rare")
+    assert pp.encode("C26", "never-seen") == 0
+    pp.save(tmp_path / "pp.json")
+    assert json.load(open(tmp_path / "pp.json"))["numerical_cols"] == [f"I{i}" for i in range(1, 14)]
+    pp2 = Preprocessor.load(tmp_path / "pp.json")
+    assert pp2.feature_dims == pp.feature_dims and np.allclose(pp2.mean, pp.mean)
+
+
+def test_struct_sizes_are_stable():
+    assert ctypes.sizeof(weights.TowerParams) % 8 == 0 and ctypes.sizeof(weights.RankerParams) % 8 == 0

@@ -136,7 +136,17 @@ int main() {
         DenseRows lx{X, rows, K, K, 30, 1ll << 30};
         run<S>("warm-up", lw, lx, EpiStore{Y, 256, rows}, K, 256, rows);
     }
+    using S64 = Shape<2, 2, 4, 1>;     // 256 x 64 tile, 64 acc regs
+    using S64b = Shape<4, 1, 2, 2>;    // 256 x 64 tile, waves split over features only
     for (int rep = 0; rep < 2; ++rep)
+        for (int K : {256, 1024}) {
+            DenseRows lw{W, 256, K, K, 30, 1ll << 30};
+            DenseRows lx{X, rows, K, K, 30, 1ll << 30};
+            run<S>("256x128 (2 wg/CU): real loads, full-line store", lw, lx, EpiStoreLines{Y, 256, rows}, K, 256, rows);
+            run<S64>("256x64 <2,2,4,1>: real loads, full-line store", lw, lx, EpiStoreLines{Y, 256, rows}, K, 256, rows);
+            run<S64b>("256x64 <4,1,2,2>: real loads, full-line store", lw, lx, EpiStoreLines{Y, 256, rows}, K, 256, rows);
+        }
+    for (int rep = 0; rep < 0; ++rep)
         for (int K : {256, 1024})
             for (int pad : {0, 8, 32, 96}) {      // leading dimension K + pad floats (power-of-two stride vs padded)
                 char lab[64];
