@@ -313,6 +313,33 @@ class FAISSIndex:
                 "is_trained": self._trained, "nlist": self.nlist, "nprobe": self.nprobe}
 
 
+def benchmark_faiss_index(dimension: int = 256, num_vectors: int = 1000000, num_queries: int = 100, k: int = 100,
+                          device="cuda", seed: int = 1234):
+    """The reference's only benchmark (faiss_retrieval.py:372-436): random corpus, add + search timings per
+    index type.  The Flat and IVF arms are built here (IVFPQ / HNSW are outside the hot path); vectors and
+    queries are drawn on the device (randn, as :390-391, seeded here)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    vectors = torch.randn((num_vectors, dimension), generator=g, device=device)
+    queries = torch.randn((num_queries, dimension), generator=g, device=device)
+    results = {}
+    for index_type, config in (("Flat", {}), ("IVF", {"nlist": 100, "nprobe": 10})):
+        idx = FAISSIndex(dimension, index_type=index_type, device=device, **config)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        idx.add(vectors)
+        torch.cuda.synchronize()
+        add_time = time.time() - t0
+        idx.search_device(queries, k)                                  # warm-up (lists, workspace)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        idx.search_device(queries, k)
+        torch.cuda.synchronize()
+        ms = (time.time() - t0) * 1000
+        results[index_type] = {"add_time": add_time, "search_time_ms": ms, "per_query_ms": ms / num_queries}
+    return results
+
+
 def flat_search(xb: torch.Tensor, n: int, q: torch.Tensor, k: int, out_scores: torch.Tensor,
                 out_pos: torch.Tensor, pos_offset: int = 0, n_fixup: Optional[torch.Tensor] = None):
     """amdrec_flat_search on device tensors (rows of xb[:n] and q already L2-normalised)."""

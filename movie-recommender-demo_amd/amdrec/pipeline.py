@@ -223,6 +223,42 @@ class AdRecommenderInference:
         return res
 
 
+class TwoStageRetriever:
+    """Drop-in for faiss_retrieval.py:259-369: the reference's second caller of the same path, taking tensors
+    instead of dicts.  ``retrieve_and_rank`` keeps the reference's signature and tuple-of-lists return.
+    ``ad_features_lookup``: None -> stage 1 only, returns (candidate ids, distances) exactly like the reference
+    (:329-331); otherwise the ``[N, n_ad_feat]`` integer table of ad features indexed by corpus position (the
+    reference collects per-id dicts and then scores all-zero placeholders, :338-345 - a documented stub)."""
+
+    def __init__(self, two_tower_model: TwoTowerModel, transformer_ranker: TransformerRanker, faiss_index: FAISSIndex,
+                 device: str = "cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.AmdrecError("TwoStageRetriever needs a HIP device (no CPU fallback)")
+        self.two_tower_model = two_tower_model.to(self.device).eval()
+        self.transformer_ranker = transformer_ranker.to(self.device).eval()
+        self.faiss_index = faiss_index
+        self._rec = None
+
+    @torch.no_grad()
+    def retrieve_and_rank(self, user_categorical: torch.Tensor, user_numerical: torch.Tensor, stage1_k: int = 500,
+                          stage2_k: int = 10, ad_features_lookup=None):
+        uc = user_categorical.to(self.device)
+        un = user_numerical.to(self.device, dtype=torch.float32)
+        if ad_features_lookup is None:                                            # :329-331
+            emb = self.two_tower_model.get_user_embeddings(uc, un)
+            ids, dist = self.faiss_index.search_device(emb, stage1_k)
+            return ids[0].tolist(), dist[0].tolist()
+        if self._rec is None or self._rec_table is not ad_features_lookup:
+            self._rec = AdRecommenderInference(device=str(self.device), two_tower_model=self.two_tower_model,
+                                               transformer_ranker=self.transformer_ranker,
+                                               faiss_index=self.faiss_index, ad_features=ad_features_lookup)
+            self._rec_table = ad_features_lookup
+        out = self._rec.recommend_device(uc[:1], un[:1], stage2_k, stage1_k, check_indices=True)
+        ctr = out["scores"][out["tasks"].index("ctr"), 0]
+        return out["ad_ids"][0].tolist(), ctr.tolist()                            # :359-369 (ids, ctr probabilities)
+
+
 class GraphedRecommender:
     """hipGraph replay of AdRecommenderInference.recommend_device for one (batch, top_k, stage1_k) shape.
     The graph owns everything its kernel nodes point at: static input/output tensors (torch's graph

@@ -127,6 +127,23 @@ def test_hipgraph_replay_equals_eager():
     assert torch.equal(a["ad_ids"], b["ad_ids"]) and torch.equal(a["candidate_scores"], b["candidate_scores"])
 
 
+def test_two_stage_retriever_and_benchmark_helper():
+    from amdrec.index import benchmark_faiss_index
+    from amdrec.pipeline import TwoStageRetriever
+    rec, (tt_sd, rk_sd, oidx, ad_table), (user, ad, nnum) = _setup(5000, 1.0 / 16)
+    r = TwoStageRetriever(rec.two_tower_model, rec.transformer_ranker, rec.faiss_index)
+    uc, un = synth.user_batch(user, nnum, 1, seed=8)
+    ids1, d1 = r.retrieve_and_rank(torch.from_numpy(uc), torch.from_numpy(un), stage1_k=100)       # stage 1 only
+    assert len(ids1) == 100 == len(d1) and d1 == sorted(d1, reverse=True)
+    ids, scores = r.retrieve_and_rank(torch.from_numpy(uc), torch.from_numpy(un), stage1_k=500, stage2_k=10,
+                                      ad_features_lookup=ad_table)
+    ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, 10, 500)[0]
+    assert len(ids) == 10 and len(set(ids) & set(ref["ad_ids"])) >= 9
+    assert np.allclose(sorted(scores, reverse=True), scores) and all(0 <= s <= 1 for s in scores)
+    res = benchmark_faiss_index(dimension=64, num_vectors=20000, num_queries=10, k=10)
+    assert set(res) == {"Flat", "IVF"} and all(set(v) == {"add_time", "search_time_ms", "per_query_ms"} for v in res.values())
+
+
 def test_index_save_load_roundtrip(tmp_path):
     rec, (tt_sd, rk_sd, oidx, ad_table), (user, ad, nnum) = _setup(2000, 1.0 / 16)
     from amdrec.index import FAISSIndex
