@@ -142,6 +142,12 @@ typedef struct {
     const int32_t* cards;           /* device [n_user_feat + n_ad_feat] */
     const float* w_proj;            /* [d_model][ldw_proj], columns = [user emb | ad emb | numerical] */
     const float* b_proj;            /* bias + positional_encoding[0,0,:] */
+    /* Optional split of w_proj for the broadcast form (user_rowdiv > 1): the [user emb | numerical] columns
+     * and the [ad emb] columns as two matrices.  When both are set the user part is computed once per USER
+     * row and added to each of its candidates' ad part (transformer_ranker.py:355 is linear in its input). */
+    const float* w_proj_user;       /* [d_model][ldw_proj_user] or NULL */
+    const float* w_proj_ad;         /* [d_model][ldw_proj_ad]   or NULL */
+    int32_t ldw_proj_user, ldw_proj_ad;
     amdrec_encoder_layer layers[AMDREC_MAX_LAYERS];
     const float* cross_wt[AMDREC_MAX_LAYERS];  /* cross_weights[i]^T : [out][ldw_cross] */
     const float* cross_b[AMDREC_MAX_LAYERS];

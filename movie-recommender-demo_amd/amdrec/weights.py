@@ -35,6 +35,7 @@ class RankerParams(C.Structure):
                 ("ldw_proj", C.c_int32), ("ldw_cross", C.c_int32), ("ldw_head1", C.c_int32),
                 ("ldw_head2", C.c_int32),
                 ("tables", _FP), ("table_off", _FP), ("cards", _FP), ("w_proj", _FP), ("b_proj", _FP),
+                ("w_proj_user", _FP), ("w_proj_ad", _FP), ("ldw_proj_user", C.c_int32), ("ldw_proj_ad", C.c_int32),
                 ("layers", EncoderLayer * MAX_LAYERS),
                 ("cross_wt", _FP * MAX_LAYERS), ("cross_b", _FP * MAX_LAYERS),
                 ("head_w1", _FP), ("head_b1", _FP),
@@ -143,6 +144,13 @@ def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int
     p.d_model = d_model
     w, p.ldw_proj = _pad_k(wproj)
     p.w_proj = pk.ptr(w)
+    # split for the broadcast form: [user emb | numerical] and [ad emb] column blocks
+    nu, na = len(user_names) * emb_dim, len(ad_names) * emb_dim
+    if nu + n_num > 0 and na > 0:
+        w, p.ldw_proj_user = _pad_k(np.concatenate([wproj[:, :nu], wproj[:, nu + na:]], axis=1))
+        p.w_proj_user = pk.ptr(w)
+        w, p.ldw_proj_ad = _pad_k(wproj[:, nu:nu + na])
+        p.w_proj_ad = pk.ptr(w)
     pos0 = _np64(sd["positional_encoding"])[0, 0]                  # only row 0 is ever read (:361)
     p.b_proj = pk.ptr((_np64(sd["feature_projection.bias"]) + pos0).astype(np.float32))
     l = 0

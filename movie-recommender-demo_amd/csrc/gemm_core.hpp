@@ -47,11 +47,16 @@ struct DenseRows {
     // Branch-free staging: rows past the end are CLAMPED to the last row (their accumulator rows are
     // never stored or emitted: every epilogue guards on the row index), the K-range test is the same for
     // all rows of a K-step and is hoisted by the caller (k_valid).  Requires rows >= 1.
-    __device__ __forceinline__ bool k_valid(int k) const { return k < K; }
-    __device__ __forceinline__ f32x4 load(long long r, int k) const {
+    // Per-row state: everything about a staged row that does not depend on k is computed ONCE before the
+    // K loop (a thread stages the same rows in every K-step).
+    using RowState = int;                        // clamped, mapped row (rows < 2^31: checked by the entry points)
+    __device__ __forceinline__ RowState row_state(long long r) const {
         long long a = map(r);
-        a = a < rows ? a : rows - 1;
-        return *reinterpret_cast<const f32x4*>(base + a * ld + k);
+        return (int)(a < rows ? a : rows - 1);
+    }
+    __device__ __forceinline__ bool k_valid(int k) const { return k < K; }
+    __device__ __forceinline__ f32x4 load(RowState a, int k) const {
+        return *reinterpret_cast<const f32x4*>(base + (long long)a * ld + k);
     }
 };
 
@@ -76,22 +81,23 @@ struct EmbConcatRows {
     int F, F0, E, eshift;       // E == 1 << eshift
     int n_num;
     int cat0_rowdiv;            // > 1: one user row broadcast over cat0_rowdiv candidate rows
-    __device__ __forceinline__ bool k_valid(int) const { return true; }   // the K tail is handled per segment
-    __device__ __forceinline__ f32x4 load(long long r, int k) const {
-        f32x4 z{0.f, 0.f, 0.f, 0.f};
-        r = r < rows ? r : rows - 1;              // clamped (see DenseRows::load)
+    // Row state: the user row (one division) and the ad-feature row (one rowmap load, clamped) are resolved
+    // once per staged row, not once per K-step: what remains per K-step is index -> table row, two loads.
+    struct RowState { int u, a; };
+    __device__ __forceinline__ RowState row_state(long long r) const {
+        r = r < rows ? r : rows - 1;              // clamped (see DenseRows)
         const long long gr = row_base + r;
+        long long r1 = rowmap1 ? rowmap1[gr] : gr;
+        r1 = r1 < 0 ? 0 : (r1 >= rows1 ? rows1 - 1 : r1);
+        return RowState{(int)(gr / cat0_rowdiv), (int)r1};
+    }
+    __device__ __forceinline__ bool k_valid(int) const { return true; }   // the K tail is handled per segment
+    __device__ __forceinline__ f32x4 load(RowState rs, int k) const {
+        f32x4 z{0.f, 0.f, 0.f, 0.f};
         const int fe = F << eshift;
         if (k < fe) {
             const int f = k >> eshift;
-            long long idx;
-            if (f < F0) {
-                idx = cat0[(gr / cat0_rowdiv) * F0 + f];
-            } else {
-                long long r1 = rowmap1 ? rowmap1[gr] : gr;
-                r1 = r1 < 0 ? 0 : (r1 >= rows1 ? rows1 - 1 : r1);
-                idx = cat1[r1 * (F - F0) + (f - F0)];
-            }
+            long long idx = (f < F0) ? cat0[(long long)rs.u * F0 + f] : cat1[(long long)rs.a * (F - F0) + (f - F0)];
             const long long hi = card[f] - 1;
             idx = idx < 0 ? 0 : (idx > hi ? hi : idx);
             return *reinterpret_cast<const f32x4*>(tables + (((long long)off[f] + idx) << eshift) +
@@ -99,7 +105,7 @@ struct EmbConcatRows {
         }
         const int j = k - fe;
         if (num == nullptr || j >= n_num) return z;
-        const float* p = num + (gr / cat0_rowdiv) * n_num;
+        const float* p = num + (long long)rs.u * n_num;
         z[0] = p[j];
         if (j + 1 < n_num) z[1] = p[j + 1];
         if (j + 2 < n_num) z[2] = p[j + 2];
@@ -173,16 +179,22 @@ __device__ __forceinline__ void gemm_block(const LoadP& lp, const LoadQ& lq, con
     constexpr int NP = BP / RPP, NQ = (BQ + RPP - 1) / RPP;
     constexpr bool QPART = BQ % RPP != 0;            // Q tile shorter than one staging pass (small-M shapes)
     f32x4 rp[NP], rq[NQ];
+    typename LoadP::RowState ps[NP];
+    typename LoadQ::RowState qs[NQ];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) ps[u] = lp.row_state(prow0 + srow + RPP * u);
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) qs[u] = lq.row_state(qrow0 + ((!QPART || srow + RPP * u < BQ) ? srow + RPP * u : 0));
 
     auto stage_load = [&](int kt) {
         const int k = kt * BK + schunk * 4;
         const bool pv = lp.k_valid(k), qv = lq.k_valid(k);
 #pragma unroll
-        for (int u = 0; u < NP; ++u) rp[u] = pv ? lp.load(prow0 + srow + RPP * u, k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NP; ++u) rp[u] = pv ? lp.load(ps[u], k) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NQ; ++u)
             if (!QPART || srow + RPP * u < BQ)
-                rq[u] = qv ? lq.load(qrow0 + srow + RPP * u, k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                rq[u] = qv ? lq.load(qs[u], k) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto stage_store = [&](int buf) {
         float* sp = smem + buf * S::STAGE_FLOATS;

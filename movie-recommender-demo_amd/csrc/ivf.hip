@@ -70,10 +70,11 @@ struct GatherRows {
     const long long* idx;   // row r of the group -> base[idx[r]]
     long long n;
     int ld, K;
+    using RowState = int;                     // the gathered row, resolved once per staged row
+    __device__ __forceinline__ RowState row_state(long long r) const { return (int)idx[r < n ? r : n - 1]; }
     __device__ __forceinline__ bool k_valid(int k) const { return k < K; }
-    __device__ __forceinline__ f32x4 load(long long r, int k) const {
-        r = r < n ? r : n - 1;
-        return *reinterpret_cast<const f32x4*>(base + idx[r] * ld + k);
+    __device__ __forceinline__ f32x4 load(RowState row, int k) const {
+        return *reinterpret_cast<const f32x4*>(base + (long long)row * ld + k);
     }
 };
 

@@ -17,6 +17,8 @@ ProfScope::~ProfScope() {}
 struct NullRows {   // no memory traffic: operand values come from registers
     float v;
     static constexpr bool can_dma = false;
+    using RowState = long long;
+    __device__ __forceinline__ RowState row_state(long long r) const { return r; }
     __device__ __forceinline__ bool k_valid(int) const { return true; }
     __device__ __forceinline__ f32x4 load(long long r, int k) const {
         float x = v + (float)(r & 7) * 0.125f + (float)(k & 31) * 0.01f;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_dma_kernel(DenseRows lp, LoadQ 
     auto load_q = [&](int kt) {
         const int k = kt * BK + schunk * 4;
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) rq[u] = lq.load(qrow0 + srow + RPP * u, k);
+        for (int u = 0; u < NQ; ++u) rq[u] = lq.load(lq.row_state(qrow0 + srow + RPP * u), k);
     };
     auto store_q = [&]() {
 #pragma unroll
