@@ -23,7 +23,7 @@ def short(name):
     e = re.search(r"amdrec::(Epi\w+)", name)
     if m and e:
         wp, wq, tp, tq = (int(m.group(i)) for i in range(1, 5))
-        epi = {"EpiLinearT": "linear", "EpiResidualLNT": "residual_ln", "EpiCrossT": "cross", "EpiL2NormT": "l2norm",
+        epi = {"EpiLinearT": "linear", "EpiRowBiasT": "linear", "EpiResidualLNT": "residual_ln", "EpiCrossT": "cross", "EpiL2NormT": "l2norm",
                "EpiFilter": "search_filter", "EpiStoreScores": "search_sample"}.get(e.group(1), e.group(1))
         gather = "_gather" if "EmbConcatRows" in name else ""
         return f"{epi}{gather}_{32 * wp * tp}x{32 * wq * tq}"
