@@ -74,3 +74,47 @@ def test_cpu_tensors_are_refused_not_silently_computed():
     from amdrec import _lib
     with pytest.raises(_lib.AmdrecError):
         _lib.require_gpu(torch.zeros(3), "x")
+
+
+def test_host_only_entry_points_validate_arguments_without_a_gpu():
+    """Workspace queries and argument validation return before any HIP call: exercised on CPU."""
+    import ctypes as C
+    from amdrec import _lib
+    lib = _lib.load()
+    n = C.c_size_t(0)
+    # search workspace: grows with nq and k, covers the candidate lists
+    assert lib.amdrec_flat_search_workspace(512, 1_000_000, 500, C.byref(n)) == 0
+    big = n.value
+    assert big >= 512 * 8192 * 8
+    assert lib.amdrec_flat_search_workspace(1, 1_000_000, 500, C.byref(n)) == 0 and n.value < big
+    assert lib.amdrec_flat_search_workspace(1, 100, 0, C.byref(n)) == -1          # k out of range
+    assert b"k=0" in lib.amdrec_last_error()
+    assert lib.amdrec_flat_search_workspace(1, 100, _lib.MAX_K + 1, C.byref(n)) == -1
+    # search: bad arguments are refused before anything is launched
+    assert lib.amdrec_flat_search(None, 10, 256, 250, None, 1, 256, 5, 0, None, None, None, 0, None, None) == -1
+    assert b"multiple of 4" in lib.amdrec_last_error()
+    assert lib.amdrec_flat_search(None, 10, 256, 256, None, 0, 256, 5, 0, None, None, None, 0, None, None) == 0   # nq = 0
+    assert lib.amdrec_flat_search(None, 10, 256, 256, None, 1, 256, 5, 0, None, None, None, 0, None, None) == -1  # nulls
+    assert lib.amdrec_l2_normalize(None, 256, None, 256, 0, 256, None) == 0        # rows = 0: nothing to do
+    assert lib.amdrec_l2_normalize(None, 256, None, 256, 4, 255, None) == -1
+    assert lib.amdrec_select_topk(None, 0, 3, 5, None, 1, 500, 10, None, None, None, None) == -1   # bad task index
+    assert lib.amdrec_topk_merge(None, None, 40, 96, 0, 1, 500, None, None, None) == -1            # 40*500 > 16384
+    assert lib.amdrec_ivf_select(None, 0, None, 0, 10, None, None, None) == 0                      # nq = 0
+
+
+def test_model_workspace_queries_follow_the_architecture():
+    import ctypes as C
+    from amdrec import _lib, synth, weights
+    lib = _lib.load()
+    user, ad, nnum = synth.demo_dims()
+    n = C.c_size_t(0)
+    p, _ = weights.pack_tower(synth.two_tower_state(user, ad, nnum, seed=1), "ad_tower", list(ad), 0, "cpu")
+    assert lib.amdrec_tower_workspace(C.byref(p), 1000, C.byref(n)) == 0
+    assert n.value >= 2 * 1000 * 512 * 4                   # two ping-pong buffers of the widest hidden layer
+    p.n_layers = 99
+    assert lib.amdrec_tower_workspace(C.byref(p), 1000, C.byref(n)) == -1 and b"n_layers" in lib.amdrec_last_error()
+    rp, _, _ = weights.pack_ranker(synth.ranker_state(user, ad, nnum, seed=2), list(user), list(ad), nnum, "cpu")
+    assert lib.amdrec_ranker_workspace(C.byref(rp), 500, C.byref(n)) == 0
+    assert n.value >= 500 * (3 * 256 + 1024) * 4
+    rp.d_model = 512
+    assert lib.amdrec_ranker_workspace(C.byref(rp), 500, C.byref(n)) == -1 and b"d_model" in lib.amdrec_last_error()
