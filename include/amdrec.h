@@ -75,9 +75,10 @@ int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t*
 
 /* Cross-shard merge (absent in the single-device reference): for queries
  * [q0, q0+nq) merge n_lists per-shard top-k lists (scores/positions of list g start
- * g*list_stride_bytes after the base pointers; each list is [nq_total][k]; positions are global,
- * -1 = unfilled) into the global top-k, same order rule as amdrec_flat_search.  n_lists*k <= 16384. */
-int amdrec_topk_merge(const float* scores, const int64_t* pos, int n_lists, int64_t list_stride_bytes,
+ * g*list_stride_bytes after the base pointers; each list is [nq_total][k]; positions are global int32
+ * (the exchange format: 8 bytes per candidate on the wire), -1 = unfilled) into the global top-k, same
+ * order rule as amdrec_flat_search.  n_lists*k <= 16384. */
+int amdrec_topk_merge(const float* scores, const int32_t* pos, int n_lists, int64_t list_stride_bytes,
                       int64_t q0, int64_t nq, int k, float* out_scores /*[nq][k]*/,
                       int64_t* out_pos /*[nq][k]*/, void* stream);
 

@@ -7,8 +7,8 @@ rows [offset_r, offset_r + n_r); weights and the ad-feature table are replicated
   1. every rank encodes the GLOBAL user batch (the tower is 0.26 GFLOP per 512 users - cheaper
      than broadcasting embeddings) and searches ITS shard for all users -> [B_g, k] scores and
      global positions;
-  2. ONE all-gather of a packed per-rank buffer [scores f32 | positions i64] (12 B per
-     candidate; 3.07 MB per rank at 512 x 500) - one fused collective instead of two; the
+  2. ONE all-gather of a packed per-rank buffer [scores f32 | global positions i32] (8 B per
+     candidate; 2.05 MB per rank per 512 users x 500) - one fused collective instead of two; the
      payload is latency-bound on xGMI, so no ring-sized bucketing is needed;
   3. rank r merges the world's lists for ITS contiguous slice of users (G*k -> k, exact, same
      order rule as the single-GPU search: the result is bit-identical to an unsharded search);
@@ -36,9 +36,10 @@ def user_slice(n_users: int, rank: int, world: int):
 
 
 def packed_layout(n_users: int, k: int):
-    """Byte layout of one rank's all-gather chunk: [scores f32 [B,k] | pad | positions i64 [B,k]]."""
-    s_bytes = (n_users * k * 4 + 7) // 8 * 8
-    return s_bytes, s_bytes + n_users * k * 8
+    """Byte layout of one rank's all-gather chunk: [scores f32 [B,k] | global positions i32 [B,k]]
+    (corpus positions are < 2^31: amdrec_flat_search refuses larger shards).  -> (offset of positions, bytes)"""
+    s_bytes = n_users * k * 4
+    return s_bytes, 2 * s_bytes
 
 
 class HipEngine:
@@ -96,7 +97,7 @@ class ShardedRecommender:
         s_bytes, chunk = packed_layout(B, k)
         buf = torch.empty(chunk, dtype=torch.uint8, device=scores.device)
         buf[:B * k * 4].view(torch.float32).copy_(scores.reshape(-1))
-        buf[s_bytes:].view(torch.int64).copy_(pos.reshape(-1))
+        buf[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))        # int64 -> int32 on the wire
         gathered = torch.empty(chunk * self.world, dtype=torch.uint8, device=scores.device)
         all_gather_bytes(gathered, buf, self.group)                           # ONE collective per step
         q0, nq = user_slice(B, self.rank, self.world)

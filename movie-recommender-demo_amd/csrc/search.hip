@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, con
         if (i < total) {
             const int g = i / k, j = i - g * k;
             const float* sg = reinterpret_cast<const float*>(scores + (long long)g * list_stride_bytes);
-            const long long* pg = reinterpret_cast<const long long*>(pos + (long long)g * list_stride_bytes);
+            const int* pg = reinterpret_cast<const int*>(pos + (long long)g * list_stride_bytes);
             const long long p = pg[(q0 + q) * k + j];
             const float sc = sg[(q0 + q) * k + j];
             if (p >= 0 && sc == sc) key = make_key(sc, (uint32_t)p);
@@ -328,11 +328,11 @@ static hipError_t run_passes(const float* X, long long ldx, long long nrows, int
 
 using namespace amdrec;
 
-extern "C" int amdrec_topk_merge(const float* scores, const int64_t* pos, int n_lists, int64_t list_stride_bytes,
+extern "C" int amdrec_topk_merge(const float* scores, const int32_t* pos, int n_lists, int64_t list_stride_bytes,
                                  int64_t q0, int64_t nq, int k, float* out_scores, int64_t* out_pos,
                                  void* stream) {
     REQUIRE(n_lists >= 1 && k >= 1 && (long long)n_lists * k <= 16384, "n_lists*k must be in [1,16384]");
-    REQUIRE(list_stride_bytes % 8 == 0 && q0 >= 0, "bad stride/offset");
+    REQUIRE(list_stride_bytes % 4 == 0 && q0 >= 0, "bad stride/offset");
     if (nq <= 0) return AMDREC_OK;
     REQUIRE(scores && pos && out_scores && out_pos, "null pointer");
     int P = 2;

@@ -40,7 +40,7 @@ class OracleEngine:
         for g in range(world):
             c = raw[g * chunk:(g + 1) * chunk]
             Ds.append(c[:n_users * k * 4].view(np.float32).reshape(n_users, k)[q0:q0 + nq])
-            Is.append(c[s_bytes:].view(np.int64).reshape(n_users, k)[q0:q0 + nq])
+            Is.append(c[s_bytes:].view(np.int32).reshape(n_users, k)[q0:q0 + nq].astype(np.int64))
         D, I = oracle.search.merge_shards(Ds, Is, [0] * world, k)
         return torch.from_numpy(D), torch.from_numpy(I)
 
@@ -132,4 +132,4 @@ def test_user_slice_and_layout():
     assert [user_slice(3, r, 4) for r in range(4)] == [(0, 1), (1, 1), (2, 1), (3, 0)]
     assert [user_slice(4096, r, 8) for r in range(8)] == [(512 * r, 512) for r in range(8)]
     s, c = packed_layout(7, 5)
-    assert s % 8 == 0 and s >= 7 * 5 * 4 and c == s + 7 * 5 * 8
+    assert s == 7 * 5 * 4 and c == 2 * s

@@ -32,7 +32,7 @@ def test_merge_of_shard_topk_is_bit_identical_to_unsharded_search():
         pos, sc = sh.search_device(q, k, return_positions=True, pos_offset=lo)
         c = gathered[g * chunk:(g + 1) * chunk]
         c[:nq * k * 4].view(torch.float32).copy_(sc.reshape(-1))
-        c[s_bytes:].view(torch.int64).copy_(pos.reshape(-1))
+        c[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))
     eng = HipEngine(None, 0)
     for q0, m in ((0, nq), (5, 11), (36, 1)):
         sc, pos = eng.merge(gathered, G, nq, k, q0, m)
@@ -45,7 +45,7 @@ def test_merge_of_shard_topk_is_bit_identical_to_unsharded_search():
         pos, sc = sh.search_device(q, k, return_positions=True, pos_offset=lo)
         c = tiny[g * chunk:(g + 1) * chunk]
         c[:nq * k * 4].view(torch.float32).copy_(sc.reshape(-1))
-        c[s_bytes:].view(torch.int64).copy_(pos.reshape(-1))
+        c[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))
     sm = FAISSIndex(256, index_type="Flat")
     sm.add(xb[:700])
     rp, rs = sm.search_device(q, k, return_positions=True)
