@@ -5,7 +5,7 @@
 //   1. sample pass : scores of every query against an evenly spaced subset of corpus tiles
 //                    (fp32 MFMA GEMM, dense store)                     ~3 % of the corpus
 //   2. threshold   : per query tau_q ~ the r-th largest sample score (r-th largest of 256 per-thread
-//                    maxima); the expected number of corpus rows with score >= tau_q is ~max(2k, k+1500)
+//                    maxima); the expected number of corpus rows with score >= tau_q is ~max(2k, k+900)
 //   3. filter pass : fp32 MFMA GEMM over the whole corpus; the epilogue appends
 //                    (score, row) keys with score >= tau_q to a per-query candidate list
 //   4. finalize    : per query, if k <= count <= capacity the exact top-k is inside the
@@ -272,7 +272,9 @@ struct SearchPlan {
 
 static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl) {
     long long nt = (nrows + SAMPLE_G - 1) / SAMPLE_G;
-    long long target = (2ll * k > k + 1500ll) ? 2ll * k : k + 1500ll;
+    // expected candidates per query: far enough above k that an unlucky sample cannot undershoot it (the
+    // estimate's sigma is ~target/8), small enough that the finalize sort stays at 2048 keys for k = 500
+    long long target = (2ll * k > k + 900ll) ? 2ll * k : k + 900ll;
     if (nrows <= CAND_CAP) {
         pl.n_sample = 0;                  // every row becomes a candidate
         pl.gstride = SAMPLE_G;

@@ -42,23 +42,24 @@ __device__ inline int find_bin_desc(const int* hist, int& r, int* scratch /*[NT+
     return bin;
 }
 
-// Bitonic sort of P (power of two) 64-bit keys in LDS, descending.  All threads call; blockDim.x must be
-// a multiple of 64.  A compare-exchange pair (i, i ^ st) with st < 64 lies inside one wave's 64 consecutive
-// elements of an iteration, and a wave's LDS operations execute in order, so those stages need only a
-// wave-level fence; block barriers are paid only for st >= 64 (15 instead of 66 for 2048 keys).
+// Bitonic sort of P (power of two) 64-bit keys in LDS, descending.  All threads call; blockDim.x must be a
+// multiple of 64.  The network is indexed by compare-exchange PAIR (pair p -> elements i, i | st with the st
+// bit spliced out of p), so every lane does useful work.  A pair with st < 32 lies inside the 64 consecutive
+// elements owned by one wave's pair group, and a wave's LDS operations execute in order, so those stages need
+// only a wave-level fence; block barriers are paid for st >= 32 and at the end of each outer stage.
 __device__ inline void bitonic_desc(unsigned long long* buf, int P) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int half = P >> 1;
     for (int sz = 2; sz <= P; sz <<= 1) {
         for (int st = sz >> 1; st > 0; st >>= 1) {
-            for (int i = tid; i < P; i += nt) {
-                int j = i ^ st;
-                if (j > i) {
-                    unsigned long long a = buf[i], b = buf[j];
-                    bool desc = (i & sz) == 0;
-                    if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[j] = a; }
-                }
+            for (int p = tid; p < half; p += nt) {
+                const int i = ((p & ~(st - 1)) << 1) | (p & (st - 1));
+                const int j = i | st;
+                const unsigned long long a = buf[i], b = buf[j];
+                const bool desc = (i & sz) == 0;
+                if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[j] = a; }
             }
-            if (st >= 64 || st == 1) __syncthreads();     // st == 1 ends an outer stage: next sz starts at st >= 1 pairs
+            if (st >= 32 || st == 1) __syncthreads();
             else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
