@@ -195,6 +195,11 @@ typedef struct {
 int amdrec_profile_enable(int on);   /* also clears the counters */
 int amdrec_profile_report(amdrec_profile_entry* out /*host*/, int max_entries, int* n /*host*/);
 
+/* Request-side numerical prep (inference.py:186-195): out[r][c] = (log1p(|x[r][c]|) - mean[c]) / scale[c],
+ * float32 (the reference produces float64 there and crashes its own float32 model). out may alias x. */
+int amdrec_prep_numerical(const float* x, const float* mean /*[cols]*/, const float* scale /*[cols]*/,
+                          float* out, int64_t rows, int cols, void* stream);
+
 /* Stage-2 selection (inference.py:258-263: sigmoid -> np.argsort(ctr)[::-1][:top_k]): per user
  * the top_k of its k_c candidates by the LOGIT of task `rank_task` (sigmoid is monotone), order
  * (logit desc, candidate slot asc).  out_ids[u][i] = cand_ids[u][slot], out_scores[t][u][i] =

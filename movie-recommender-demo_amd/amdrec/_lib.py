@@ -43,6 +43,7 @@ _SIGNATURES = {
     "amdrec_remap_ids": [_vp, _vp, _i64, _vp, _i64, _vp],
     "amdrec_profile_enable": [_i32],
     "amdrec_profile_report": [_vp, _i32, C.POINTER(_i32)],
+    "amdrec_prep_numerical": [_fp, _fp, _fp, _fp, _i64, _i32, _vp],
     "amdrec_select_topk": [_fp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _fp, _vp, _vp],
 }
 _RESTYPE = {"amdrec_last_error": C.c_char_p}

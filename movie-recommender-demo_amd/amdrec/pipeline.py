@@ -132,6 +132,30 @@ class AdRecommenderInference:
         num = ((num - pp.mean) / pp.scale).astype(np.float32)
         return torch.tensor([cat], dtype=torch.long), torch.from_numpy(num[None, :])
 
+    def preprocess_batch(self, user_data_list: list):
+        """Batch form of preprocess_user_features with the numerical transform on the device: categorical strings
+        are label-encoded on the host (dictionary lookups), raw numericals are shipped as one float32 block and
+        log1p / standardised by amdrec_prep_numerical.  -> (user_categorical [B,6] int64, user_numerical [B,13]
+        float32), both on the device."""
+        pp = self.preprocessor
+        if pp is None:
+            raise ValueError("no preprocessor loaded")
+        cols = [c for c in USER_COLS if c in pp.classes]
+        cat = torch.tensor([[pp.encode(c, u["categorical"].get(c, "missing")) for c in cols] for u in user_data_list],
+                           dtype=torch.long).reshape(len(user_data_list), len(cols))
+        raw = torch.tensor([[float(u["numerical"].get(c, 0)) for c in pp.numerical_cols] for u in user_data_list],
+                           dtype=torch.float32).reshape(len(user_data_list), len(pp.numerical_cols))
+        dev = self.ad_features.device
+        if getattr(self, "_pp_dev", (None,))[0] is not pp:
+            self._pp_dev = (pp, torch.from_numpy(pp.mean.astype(np.float32)).to(dev),
+                            torch.from_numpy(pp.scale.astype(np.float32)).to(dev))
+        x = raw.to(dev)
+        out = torch.empty_like(x)
+        lib = _lib.load()
+        _lib.check(lib.amdrec_prep_numerical(_lib.ptr(x), _lib.ptr(self._pp_dev[1]), _lib.ptr(self._pp_dev[2]),
+                                             _lib.ptr(out), x.shape[0], x.shape[1], _lib.stream_ptr(dev)))
+        return cat.to(dev), out
+
     # -- the device hot path ------------------------------------------------------------------
     def _stage1(self, uc, un, stage1_k, check_indices):
         emb = self.two_tower_model.user_tower.encode(uc, un, check_indices=check_indices)      # :223-227
@@ -192,9 +216,7 @@ class AdRecommenderInference:
         ``timing`` reports the batch's stage times divided by the number of users."""
         if not user_data_list:
             return []
-        feats = [self.preprocess_user_features(u) for u in user_data_list]
-        uc = torch.cat([f[0] for f in feats])
-        un = torch.cat([f[1] for f in feats])
+        uc, un = self.preprocess_batch(user_data_list)
         return self.recommend_tensors(uc, un, top_k, stage1_k, return_scores)
 
     @torch.no_grad()

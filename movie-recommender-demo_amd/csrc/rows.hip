@@ -39,6 +39,17 @@ __global__ void remap_ids_kernel(const long long* pos, const long long* id_map, 
     out[i] = (p >= 0 && p < n_map) ? id_map[p] : -1;
 }
 
+// Request-side numerical feature prep (inference.py:186-195 / data_preprocessing.py: log1p(|x|) then
+// StandardScaler.transform): out = (log1p(|x|) - mean[c]) / scale[c], float32 out (the reference's float64
+// result crashes its own float32 model).
+__global__ void prep_numerical_kernel(const float* x, const float* mean, const float* scale, float* out, long long rows,
+                                      int cols) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int c = (int)(i % cols);
+    out[i] = (log1pf(fabsf(x[i])) - mean[c]) / scale[c];
+}
+
 // Stage-2 selection (inference.py:258-263, faiss_retrieval.py:355-358): per user, the top_k of
 // its k_c candidates by the ranking task's LOGIT (sigmoid is monotone; ranking on logits avoids
 // the ties of saturated sigmoids), order (logit desc, candidate slot asc); then sigmoid of every
@@ -90,6 +101,18 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* logits, l
 }  // namespace amdrec
 
 using namespace amdrec;
+
+extern "C" int amdrec_prep_numerical(const float* x, const float* mean, const float* scale, float* out, int64_t rows,
+                                     int cols, void* stream) {
+    REQUIRE(cols >= 1, "cols must be >= 1");
+    if (rows <= 0) return AMDREC_OK;
+    REQUIRE(x && mean && scale && out, "null pointer");
+    const long long n = rows * cols;
+    hipLaunchKernelGGL(prep_numerical_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, mean, scale, out, (long long)rows, cols);
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
 
 extern "C" int amdrec_select_topk(const float* logits, int64_t ld_logits, int n_tasks, int rank_task,
                                   const int64_t* cand_ids, int64_t n_users, int k_c, int top_k, int64_t* out_ids,

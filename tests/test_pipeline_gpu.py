@@ -100,6 +100,34 @@ def test_reference_api_schema_and_preprocessing():
     # batch == single (same kernels, deterministic)
     single = rec.batch_recommend([users[3]], top_k=7, stage1_k=100)[0]
     assert single["ad_ids"] == rs[3]["ad_ids"]
+    # device feature prep (amdrec_prep_numerical) == the host float64 transform of inference.py:186-195
+    cat_d, num_d = rec.preprocess_batch(users)
+    host = [rec.preprocess_user_features(u) for u in users]
+    assert torch.equal(cat_d.cpu(), torch.cat([h[0] for h in host]))
+    assert num_d.dtype == torch.float32 and num_d.is_cuda
+    assert (num_d.cpu() - torch.cat([h[1] for h in host])).abs().max().item() <= 5e-6
+
+
+def test_microbatcher_over_the_device_pipeline():
+    """Concurrent recommend_ads callers coalesced into batch_recommend passes return what a direct call returns."""
+    import threading
+    from amdrec.pipeline import Preprocessor
+    from amdrec.serving import MicroBatcher
+    rec, _, (user, ad, nnum) = _setup(3000, 1.0 / 16)
+    classes = {c: [f"cat_{j}" for j in range(card - 1)] + ["rare"] for c, card in user.items()}
+    rec.preprocessor = Preprocessor(classes, [f"I{i}" for i in range(1, 14)], np.full(13, 1.5), np.full(13, 0.7))
+    rng = np.random.default_rng(9)
+    users = [{"categorical": {f"C{i}": f"cat_{rng.integers(0, 50)}" for i in range(1, 7)},
+              "numerical": {f"I{i}": float(rng.random() * 100) for i in range(1, 14)}} for _ in range(24)]
+    direct = rec.batch_recommend(users, top_k=5, stage1_k=100)
+    mb = MicroBatcher(lambda us: rec.batch_recommend(us, top_k=5, stage1_k=100), max_batch=16, max_wait_ms=20)
+    out = {}
+    ts = [threading.Thread(target=lambda i=i: out.__setitem__(i, mb.recommend_ads(users[i]))) for i in range(24)]
+    [t.start() for t in ts]
+    [t.join(30) for t in ts]
+    mb.close()
+    assert all(out[i]["ad_ids"] == direct[i]["ad_ids"] for i in range(24))
+    assert sum(mb.batches) == 24 and len(mb.batches) < 24
 
 
 def test_hipgraph_replay_equals_eager():
