@@ -240,11 +240,16 @@ def main():
         search = None
         if sf:
             ms = sf["total_ms"] / sf["launches"]
-            alg_bytes = rows * DIM * 4 + B_global * DIM * 4 + B_global * STAGE1_K * 12   # this rank's shard
-            search = {"filter_pass_ms": round(ms, 3), "alg_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+            mixed = getattr(index, "_mixed", False)      # bf16 shadow corpus read by the filter pass
+            eb = 2 if mixed else 4
+            alg_bytes = rows * DIM * eb + B_global * DIM * eb       # this rank's shard, one corpus pass
+            search = {"engine": "bf16 MFMA filter + fp32 re-score + certificate" if mixed else "fp32 MFMA filter",
+                      "filter_pass_ms": round(ms, 3), "alg_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
                       "hbm_frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "tflops": round(sf["flops"] / sf["launches"] / (ms * 1e-3) / 1e12, 2),
-                      "note": "B=512 per corpus pass is fp32-FLOP bound (intensity 255 FLOP/B vs ridge 19.7)"}
+                      "note": ("filter = one pass over the bf16 corpus; B=512 queries per pass, intensity 512 FLOP/B vs "
+                               "bf16 ridge 312: MFMA/L2-feed bound, not HBM bound" if mixed else
+                               "B=512 per corpus pass is fp32-FLOP bound (intensity 255 FLOP/B vs ridge 19.7)")}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             corpus_cpu = index._xb[:index._n].cpu().numpy()
@@ -336,12 +341,15 @@ def search_sweep(index, device, reps=20):
         e1.record()
         torch.cuda.synchronize(device)
         ms = e0.elapsed_time(e1) / reps
-        alg_bytes = n * DIM * 4 + B * DIM * 4 + B * STAGE1_K * 12
+        # one corpus pass (bf16 shadow when the index runs the mixed search) + the fp32 rows of the k results
+        eb = 2 if getattr(index, "_mixed", False) else 4
+        alg_bytes = n * DIM * eb + B * DIM * 4 + B * STAGE1_K * 12 + (B * STAGE1_K * DIM * 4 if eb == 2 else 0)
         flops = 2.0 * B * n * DIM
         rows.append({"B": B, "ms": round(ms, 4), "qps": round(B / ms * 1e3, 1),
                      "alg_GBps": round(alg_bytes / ms / 1e6, 1), "hbm_frac": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                      "tflops": round(flops / ms / 1e9, 2), "fp32_frac": round(flops / ms / 1e9 / FP32_PEAK_TFLOPS, 4)})
-    print(json.dumps({f"search_sweep_{n}_k500": rows}), file=sys.stderr, flush=True)
+    print(json.dumps({f"search_sweep_{n}_k500": rows, "engine": "bf16+fp32 rescore" if eb == 2 else "fp32"}),
+          file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,22 @@ int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld_corpus, in
                        int64_t* out_pos /*[nq][k]*/, void* workspace, size_t workspace_bytes,
                        int* n_fixup, void* stream);
 
+/* Mixed-precision form of the same search (same result contract: the exact fp32 top-k).  The sample and filter
+ * passes read `corpus_bf16`, a bf16 (round-to-nearest) copy of the corpus made by amdrec_bf16_rows, with the bf16
+ * MFMA; candidates are re-scored in fp32 from `corpus` and the result is certified against the error bound
+ * eps = (2^-8 + ...) * |query| * max_norm[0]  (max_norm: device float = the largest row norm of the corpus, as
+ * accumulated by amdrec_bf16_rows); uncertified queries take the exact fp32 fix-up scan.  dim % 8 == 0.
+ * Turns the filter pass from fp32-MFMA-bound into memory-bound (half the bytes, 16x the MFMA rate). */
+int amdrec_bf16_rows(const float* x, int64_t rows, int64_t ld, int dim, uint16_t* out /*[rows][ld_out] bf16*/,
+                     int64_t ld_out, float* max_norm /*device, in/out (atomic max), may be NULL*/, void* stream);
+int amdrec_flat_search_mixed_workspace(int64_t nq, int64_t nrows, int k, int dim, size_t* bytes /*host*/);
+int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int64_t ld_corpus, int dim,
+                             const uint16_t* corpus_bf16, int64_t ld_bf16, const float* max_norm,
+                             const float* queries, int64_t nq, int64_t ld_queries, int k,
+                             int64_t pos_offset, float* out_scores /*[nq][k]*/,
+                             int64_t* out_pos /*[nq][k]*/, void* workspace, size_t workspace_bytes,
+                             int* n_fixup, void* stream);
+
 /* ---- retrieval: IVF-Flat (faiss IndexIVFFlat, METRIC_INNER_PRODUCT, IndexFlatIP quantizer:
  * faiss_retrieval.py:50-55, searched at :150-155 with index.nprobe = nprobe) ---------------------
  * Layout: corpus rows stored list-contiguous `lists[N][ld]` (list l = rows [list_off[l], list_off[l+1]))

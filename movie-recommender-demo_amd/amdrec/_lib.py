@@ -29,6 +29,10 @@ _SIGNATURES = {
     "amdrec_abi_version": [],
     "amdrec_last_error": [],
     "amdrec_flat_search_workspace": [_i64, _i64, _i32, C.POINTER(_sz)],
+    "amdrec_bf16_rows": [_fp, _i64, _i64, _i32, _vp, _i64, _fp, _vp],
+    "amdrec_flat_search_mixed_workspace": [_i64, _i64, _i32, _i32, C.POINTER(_sz)],
+    "amdrec_flat_search_mixed": [_fp, _i64, _i64, _i32, _vp, _i64, _fp, _fp, _i64, _i64, _i32, _i64, _fp, _vp, _vp,
+                                 _sz, _vp, _vp],
     "amdrec_flat_search": [_fp, _i64, _i64, _i32, _fp, _i64, _i64, _i32, _i64, _fp, _vp, _vp, _sz, _vp, _vp],
     "amdrec_ivf_scan": [_fp, _i64, _i32, _vp, _vp, _fp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _i64, _vp],
     "amdrec_ivf_scan_grouped": [_fp, _i64, _i32, _vp, _vp, _i32, _i64, _fp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32,

@@ -57,9 +57,14 @@ class _Handle:
 
 class FAISSIndex:
     def __init__(self, dimension: int, index_type: str = "IVF", nlist: int = 100, nprobe: int = 10,
-                 use_gpu: bool = False, device=None, verbose: bool = False):
+                 use_gpu: bool = False, device=None, verbose: bool = False, prefilter: str = "bf16"):
         """``use_gpu`` is accepted for signature compatibility; the index always lives on the
-        HIP device (``device`` or the current one) - there is no CPU engine."""
+        HIP device (``device`` or the current one) - there is no CPU engine.
+        ``prefilter`` (Flat only): "bf16" keeps a bf16 copy of the corpus next to the fp32 one and searches with
+        amdrec_flat_search_mixed (bf16 MFMA filter, fp32 re-score, certified exact); "fp32" = amdrec_flat_search."""
+        if prefilter not in ("bf16", "fp32"):
+            raise ValueError("prefilter must be 'bf16' or 'fp32'")
+        self.prefilter = prefilter
         self.dimension = int(dimension)
         self.index_type = index_type
         self.nlist = int(nlist)
@@ -82,6 +87,10 @@ class FAISSIndex:
         self._xb = torch.empty((0, self.dimension), dtype=torch.float32, device=self.device)
         self._ids = torch.empty((0,), dtype=torch.int64, device=self.device)
         self._n = 0
+        # bf16 shadow of the corpus + its largest row norm (the mixed search's error bound)
+        self._mixed = self.index_type == "Flat" and self.prefilter == "bf16" and self.dimension % 8 == 0
+        self._xb16 = torch.empty((0, self.dimension), dtype=torch.bfloat16, device=self.device)
+        self._maxnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._identity = True          # ids == arange(n): remap is the identity
         self._host_ids: Optional[list] = None   # only for non-integer ids
         self._trained = self.index_type == "Flat"
@@ -123,6 +132,20 @@ class FAISSIndex:
             xb[:self._n].copy_(self._xb[:self._n])
             ids[:self._n].copy_(self._ids[:self._n])
         self._xb, self._ids = xb, ids
+        if self._mixed:
+            xb16 = torch.empty((new_cap, self.dimension), dtype=torch.bfloat16, device=self.device)
+            if self._n:
+                xb16[:self._n].copy_(self._xb16[:self._n])
+            self._xb16 = xb16
+
+    def _shadow_rows(self, lo, hi):
+        """(Re)build rows [lo, hi) of the bf16 shadow from the fp32 rows and fold their norms into _maxnorm."""
+        if not self._mixed or hi <= lo:
+            return
+        lib = _lib.load()
+        x, y = self._xb[lo:hi], self._xb16[lo:hi]
+        _lib.check(lib.amdrec_bf16_rows(_lib.ptr(x), hi - lo, x.stride(0), self.dimension, _lib.ptr(y), y.stride(0),
+                                        _lib.ptr(self._maxnorm), _lib.stream_ptr(self.device)))
 
     # -- reference API ----------------------------------------------------------------
     def train(self, embeddings):
@@ -154,6 +177,7 @@ class FAISSIndex:
         x = self._xb[self._n:self._n + m]
         x.copy_(src)                                                 # casts + moves to the device
         self._normalize_(x)
+        self._shadow_rows(self._n, self._n + m)
         if ad_ids is None:                                           # :121-122
             new_ids = torch.arange(self._n, self._n + m, dtype=torch.int64, device=self.device)
             if self._host_ids is not None:
@@ -208,6 +232,9 @@ class FAISSIndex:
         if self.index_type == "IVF":
             self._ivf.search(self._xb, self._n, q, k, self.nprobe, scores, pos,
                              pos_offset=pos_offset if return_positions else 0)
+        elif self._mixed:
+            flat_search_mixed(self._xb, self._xb16, self._maxnorm, self._n, q, k, scores, pos,
+                              pos_offset=pos_offset if return_positions else 0)
         else:
             flat_search(self._xb, self._n, q, k, scores, pos, pos_offset=pos_offset if return_positions else 0)
         if return_positions or self._identity:
@@ -298,6 +325,7 @@ class FAISSIndex:
         self._xb[:n].copy_(torch.from_numpy(arrays["xb"].copy()))
         self._ids[:n].copy_(torch.from_numpy(arrays["ids"].copy()))
         self._n = n
+        self._shadow_rows(0, n)
         self._identity = header["identity_ids"]
         self._host_ids = header.get("host_ids")
         if self.index_type == "IVF":
@@ -354,3 +382,22 @@ def flat_search(xb: torch.Tensor, n: int, q: torch.Tensor, k: int, out_scores: t
         _lib.ptr(xb), n, xb.stride(0) if xb.dim() == 2 and xb.shape[0] > 0 else xb.shape[-1], xb.shape[-1],
         _lib.ptr(q), q.shape[0], q.stride(0), k, pos_offset, _lib.ptr(out_scores), _lib.ptr(out_pos),
         _lib.ptr(ws), ws.numel(), _lib.ptr(n_fixup), _lib.stream_ptr(dev)))
+
+
+def flat_search_mixed(xb: torch.Tensor, xb16: torch.Tensor, max_norm: torch.Tensor, n: int, q: torch.Tensor, k: int,
+                      out_scores: torch.Tensor, out_pos: torch.Tensor, pos_offset: int = 0,
+                      n_fixup: Optional[torch.Tensor] = None):
+    """amdrec_flat_search_mixed on device tensors: xb16 = amdrec_bf16_rows(xb), max_norm = its largest row norm."""
+    lib = _lib.load()
+    dev = q.device
+    if q.shape[0] == 0:
+        return
+    d = xb.shape[-1]
+    nbytes = _lib.C.c_size_t(0)
+    _lib.check(lib.amdrec_flat_search_mixed_workspace(q.shape[0], n, k, d, _lib.C.byref(nbytes)))
+    ws = _lib.WORKSPACE.get(nbytes.value, dev)
+    has = xb.dim() == 2 and xb.shape[0] > 0
+    _lib.check(lib.amdrec_flat_search_mixed(
+        _lib.ptr(xb), n, xb.stride(0) if has else d, d, _lib.ptr(xb16), xb16.stride(0) if has else d,
+        _lib.ptr(max_norm), _lib.ptr(q), q.shape[0], q.stride(0), k, pos_offset, _lib.ptr(out_scores),
+        _lib.ptr(out_pos), _lib.ptr(ws), ws.numel(), _lib.ptr(n_fixup), _lib.stream_ptr(dev)))

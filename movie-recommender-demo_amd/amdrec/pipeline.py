@@ -311,7 +311,7 @@ class GraphedRecommender:
         # makes the graph stale (documented) but can never leave it with dangling pointers
         idx = rec.faiss_index
         self._pinned = (rec.two_tower_model.user_tower._packed, rec.transformer_ranker._packed, idx._xb, idx._ids,
-                        rec.ad_features, getattr(idx, "_ivf", None) and idx._ivf._lists)
+                        idx._xb16, idx._maxnorm, rec.ad_features, getattr(idx, "_ivf", None) and idx._ivf._lists)
 
     @torch.no_grad()
     def __call__(self, user_categorical: torch.Tensor, user_numerical: torch.Tensor):

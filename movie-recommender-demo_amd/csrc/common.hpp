@@ -9,6 +9,7 @@ namespace amdrec {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---- error plumbing (amdrec_last_error) -------------------------------------------
 extern thread_local char g_err[512];

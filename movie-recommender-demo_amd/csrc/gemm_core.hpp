@@ -137,10 +137,16 @@ struct TileMap {
 // per CU, so one workgroup's prologue (first HBM fetch) and epilogue (stores, residual loads, reductions)
 // run under the other's MFMAs.  Measured on the 8-wave / 128 KB / one-per-CU predecessor: MFMA pipe busy
 // 0.60-0.75, falling with epilogue weight (rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES; profiles/README.md).
-template <int WP_, int WQ_, int TP_, int TQ_, bool DBUF_ = false>
+//
+// BF16 = the operands are bf16 matrices handed to the loaders as float matrices of K/2 columns (bytes are
+// bytes: the same 128-byte row segments, staging, swizzle and fragment reads); a K-step is then 64 bf16 and the
+// 16 bytes a lane reads are the 8 consecutive k of one v_mfma_f32_32x32x16_bf16 operand (lane half h reads
+// chunk 2c+h = k 16c+8h..+7, exactly the instruction's A/B lane map).  Same C/D layout, so every epilogue is
+// shared.  Used by the search prefilter only (search.hip): 16x the fp32 MFMA rate, results re-scored in fp32.
+template <int WP_, int WQ_, int TP_, int TQ_, bool DBUF_ = false, bool BF16_ = false>
 struct Shape {
     static constexpr int WP = WP_, WQ = WQ_, TP = TP_, TQ = TQ_;
-    static constexpr bool DBUF = DBUF_;
+    static constexpr bool DBUF = DBUF_, BF16 = BF16_;
     static constexpr int NT = 64 * WP * WQ;
     static constexpr int BP = WP * TP * 32, BQ = WQ * TQ * 32;
     static constexpr int STAGE_FLOATS = (BP + BQ) * BK;
@@ -238,14 +244,23 @@ __device__ __forceinline__ void gemm_block(const LoadP& lp, const LoadQ& lq, con
 #pragma unroll
             for (int j = 0; j < TQ; ++j)
                 b[j] = *reinterpret_cast<const f32x4*>(sq + lds_slot(j * 32 + frow, 2 * c + fh));
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
+            if constexpr (S::BF16) {
 #pragma unroll
                 for (int i = 0; i < TP; ++i)
 #pragma unroll
                     for (int j = 0; j < TQ; ++j)
-                        acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s],
-                                                                           acc.v[i][j], 0, 0, 0);
+                        acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc.v[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TP; ++i)
+#pragma unroll
+                        for (int j = 0; j < TQ; ++j)
+                            acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s],
+                                                                               acc.v[i][j], 0, 0, 0);
+            }
         }
         if (S::DBUF) {
             if (more) stage_store((kt + 1) & 1);
@@ -294,10 +309,12 @@ inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, 
     if (tm.tiles_small <= 0 || tm.tiles_big <= 0) return hipSuccess;
     int ksteps = (K + BK - 1) / BK;
     char tag[64];
-    if (g_prof_on) snprintf(tag, sizeof(tag), "%s_%dx%d", Epi::name, S::BP, S::BQ);
-    const double ka = k_alg > 0 ? k_alg : K;
+    if (g_prof_on) snprintf(tag, sizeof(tag), "%s_%dx%d%s", Epi::name, S::BP, S::BQ, S::BF16 ? "_bf16" : "");
+    const double ka = k_alg > 0 ? k_alg : (S::BF16 ? 2.0 * K : (double)K);    // elements, not staged floats
+    const double eb = S::BF16 ? 2.0 : 4.0;
     ProfScope prof(tag, 2.0 * (double)p_rows * (double)q_rows * ka,
-                   4.0 * ((double)p_rows * ka + (double)q_rows * ka + Epi::out_bytes_per_elem * (double)p_rows * (double)q_rows),
+                   eb * ((double)p_rows * ka + (double)q_rows * ka) +
+                       4.0 * Epi::out_bytes_per_elem * (double)p_rows * (double)q_rows,
                    stream);
     hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(S::NT), lds_bytes, stream, lp, lq, epi, ksteps, tm);
     return hipGetLastError();

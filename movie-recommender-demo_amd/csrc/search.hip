@@ -15,6 +15,17 @@
 //                    query, running threshold) + merge.  Blocks of healthy queries exit at once.
 // The result is exact for every input; only the speed depends on the data.
 // Order: score descending, equal scores -> lower row first (deterministic).
+//
+// Mixed-precision variant (amdrec_flat_search_mixed): passes 1-3 run on a bf16 copy of the corpus and of the
+// queries with v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, half the HBM bytes), which turns the filter from
+// MFMA-bound into memory-bound; the result stays the exact fp32 one because
+//   * eps_q = EPS_REL * |q| * max_row|x| bounds |approx - exact| for every row (bf16 round-to-nearest of both
+//     operands: relative 2^-9 each; Cauchy-Schwarz; plus the fp32 accumulation slack),
+//   * finalize sorts the candidates by approximate score, keeps those with approx >= a_k - 2 eps (a_k = k-th
+//     largest approx; anything below is beaten by k rows), RE-SCORES them in fp32 from the fp32 corpus, sorts again,
+//   * and certifies: every row outside the list has approx < tau, i.e. exact < tau + eps; if the k-th re-scored
+//     value is >= tau + eps nothing outside can enter the top-k.  A query that fails the certificate (or the
+//     count test) goes to the same exact fp32 fix-up scan as before.
 #include "gemm_core.hpp"
 #include "topk_utils.hpp"
 #include "../../include/amdrec.h"
@@ -256,6 +267,122 @@ __global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, con
     write_result(keys, total < k ? total : k, k, q, outD, outI, 0);
 }
 
+// fp32 rows -> bf16 rows (round to nearest even, NaN kept), one wave per row; optionally the maximum row norm
+// (atomic max over the float bits: norms are >= 0 so the unsigned order is the float order; NaN/inf propagate
+// and make every certificate fail -> exact fix-up path).
+__global__ __launch_bounds__(256) void bf16_rows_kernel(const float* x, long long rows, long long ld, int d,
+                                                        uint16_t* out, long long ld_out, float* max_norm) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float ss = 0.f;
+    for (int c = lane; c < (d >> 2); c += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + 4 * c);
+        uint32_t h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t u = __float_as_uint(v[e]);
+            h[e] = (v[e] != v[e]) ? 0x7fc0u : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            ss += v[e] * v[e];
+        }
+        uint2 pk{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        *reinterpret_cast<uint2*>(out + r * ld_out + 4 * c) = pk;
+    }
+    if (max_norm) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(max_norm), __float_as_uint(sqrtf(ss)));
+    }
+}
+
+// |approx - exact| <= EPS_REL(d) * |q| * max|x|: 2u + u^2 with u = 2^-9 (bf16 RN of both operands) = 0.0039101,
+// rounded up, plus 2 d 2^-24 for the two fp32 accumulations being compared.
+__device__ __forceinline__ float eps_rel(int d) { return 0.00392f + (float)d * 1.2e-7f; }
+
+// step 4 of the mixed-precision search: approx sort -> prune -> fp32 re-score -> exact sort -> certificate
+__global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long long* cand, const int* cnt, int cap,
+                                                             int k, long long nrows, const float* tau,
+                                                             const float* max_norm, const float* X, long long ldx,
+                                                             int d, const float* Q, long long ldq, int* fail,
+                                                             float* outD, long long* outI, long long pos_offset) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [cap] then qv[d]
+    float* qv = reinterpret_cast<float*>(keys + cap);
+    __shared__ float red[8];
+    __shared__ int m_sh;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = cnt[q];
+    const int need = (int)(nrows < k ? nrows : k);
+    auto give_up = [&]() {
+        if (tid == 0) { fail[q] = 1; atomicAdd(&fail[gridDim.x], 1); }
+    };
+    if (c < need || c > cap) { give_up(); return; }
+    float ss = 0.f;
+    for (int i = tid; i < d; i += 512) {
+        const float v = Q[(long long)q * ldq + i];
+        qv[i] = v;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (lane == 0) red[w] = ss;
+    if (tid == 0) m_sh = 0;
+    int P = 2;
+    while (P < c) P <<= 1;
+    for (int i = tid; i < P; i += 512) keys[i] = (i < c) ? cand[(long long)q * cap + i] : 0ull;
+    __syncthreads();
+    float qn = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qn += red[i];
+    const float eps = eps_rel(d) * sqrtf(qn) * max_norm[0];
+    if (!(eps < INFINITY)) { give_up(); return; }            // NaN / inf norms: exact path (block-uniform)
+    if (need == 0) { write_result(keys, 0, k, q, outD, outI, pos_offset); return; }
+    bitonic_desc(keys, P);
+    // prune: a row with approx < a_k - 2 eps has exact < a_k - eps <= exact of each of the k best-by-approx rows
+    const float cut = key_score(keys[need - 1]) - 2.f * eps;
+    for (int i = tid; i < c; i += 512)
+        if (key_score(keys[i]) >= cut && (i + 1 == c || !(key_score(keys[i + 1]) >= cut))) m_sh = i + 1;
+    __syncthreads();
+    const int m = m_sh;                                       // >= need
+    // fp32 re-score, one wave per candidate, 4 candidates in flight per wave
+    const int d4 = d >> 2;
+    for (int i0 = w; i0 < m; i0 += 32) {
+        float a[4];
+        uint32_t pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 8 * u;
+            a[u] = 0.f;
+            pos[u] = key_pos(keys[i < m ? i : i0]);
+            const f32x4* xr = reinterpret_cast<const f32x4*>(X + (long long)pos[u] * ldx);
+            for (int cc = lane; cc < d4; cc += 64) {
+                const f32x4 x = xr[cc];
+                const f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * cc]);
+                a[u] += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = a[u];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int i = i0 + 8 * u;
+            // a NaN re-score (inf - inf in fp32 that the bf16 pass did not produce) ranks last, as in the fix-up scan
+            if (lane == 0 && i < m) keys[i] = (v == v) ? make_key(v, pos[u]) : 0ull;
+        }
+    }
+    int P2 = 2;
+    while (P2 < m) P2 <<= 1;
+    __syncthreads();
+    for (int i = m + tid; i < P2; i += 512) keys[i] = 0ull;
+    __syncthreads();
+    bitonic_desc(keys, P2);
+    // certificate (block-uniform): rows outside the list have exact < tau + eps
+    const unsigned long long kth = keys[need - 1];
+    const bool all_rows = (long long)c >= nrows;
+    if (!all_rows && !(kth != 0ull && key_score(kth) >= tau[q] + eps)) { give_up(); return; }
+    write_result(keys, m, k, q, outD, outI, pos_offset);
+}
+
 __global__ void fill_f32_kernel(float* p, long long n, float v) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -267,10 +394,11 @@ struct SearchPlan {
     long long gstride;       // rows between sample blocks
     int rank;                // r
     int nslices;             // fix-up slices
-    size_t off_tau, off_cnt, off_fail, off_cand, off_sample, off_fix, bytes;
+    size_t off_tau, off_cnt, off_fail, off_cand, off_sample, off_fix, off_q16, bytes;
 };
 
-static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl) {
+// dim16 > 0: the mixed-precision search, which also keeps a bf16 copy of the queries in the workspace
+static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int dim16 = 0) {
     long long nt = (nrows + SAMPLE_G - 1) / SAMPLE_G;
     // expected candidates per query: far enough above k that an unlucky sample cannot undershoot it (the
     // estimate's sigma is ~target/8), small enough that the finalize sort stays at 2048 keys for k = 500
@@ -298,13 +426,16 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl) {
     pl.off_cand = o;   o = align_up(o + (size_t)nq * CAND_CAP * 8, 256);
     pl.off_sample = o; o = align_up(o + (size_t)nq * (size_t)pl.n_sample * 4, 256);
     pl.off_fix = o;    o = align_up(o + (size_t)nq * pl.nslices * k * 8, 256);
+    pl.off_q16 = o;    o = align_up(o + (size_t)nq * (size_t)dim16 * 2, 256);
     pl.bytes = o;
     return 0;
 }
 
+// X / Q / ldx / ldq / d are in staged floats: for a BF16 shape the bf16 matrices viewed as float matrices of
+// half the columns (d_alg = the un-halved dimension, for the profiling hook's FLOP count)
 template <class S>
 static hipError_t run_passes(const float* X, long long ldx, long long nrows, int d, const float* Q, long long ldq,
-                             int nq, const SearchPlan& pl, char* ws, hipStream_t st) {
+                             int nq, const SearchPlan& pl, char* ws, hipStream_t st, int d_alg = 0) {
     DenseRows lq{Q, nq, (int)ldq, d, 30, 1ll << 30};
     float* tau = reinterpret_cast<float*>(ws + pl.off_tau);
     int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
@@ -313,7 +444,7 @@ static hipError_t run_passes(const float* X, long long ldx, long long nrows, int
         DenseRows lps{X, nrows, (int)ldx, d, gshift, pl.gstride};
         float* S_ = reinterpret_cast<float*>(ws + pl.off_sample);
         EpiStoreScores es{S_, pl.n_sample, nq, pl.n_sample, lps};
-        hipError_t e = launch_gemm<S, false>(lps, lq, es, d, pl.n_sample, nq, st);
+        hipError_t e = launch_gemm<S, false>(lps, lq, es, d, pl.n_sample, nq, st, d_alg);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(sample_threshold_kernel, dim3(nq), dim3(256), 0, st, S_, pl.n_sample, pl.n_sample,
                            pl.rank, tau);
@@ -323,7 +454,7 @@ static hipError_t run_passes(const float* X, long long ldx, long long nrows, int
     }
     DenseRows lp{X, nrows, (int)ldx, d, 30, 1ll << 30};
     EpiFilter ef{tau, reinterpret_cast<unsigned long long*>(ws + pl.off_cand), cnt, CAND_CAP, nq, nrows};
-    return launch_gemm<S, false>(lp, lq, ef, d, nrows, nq, st);
+    return launch_gemm<S, false>(lp, lq, ef, d, nrows, nq, st, d_alg);
 }
 
 }  // namespace amdrec
@@ -408,6 +539,100 @@ extern "C" int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld
     unsigned long long* fix = reinterpret_cast<unsigned long long*>(ws + pl.off_fix);
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, cand, cnt, CAND_CAP, k,
                        (long long)nrows, fail, out_scores, (long long*)out_pos, (long long)pos_offset);
+    hipLaunchKernelGGL(fixup_scan_kernel, dim3(pl.nslices, (unsigned)nq), dim3(512), 0, st, corpus,
+                       (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, k,
+                       pl.nslices, fix);
+    hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, fix, fail, k,
+                       pl.nslices, out_scores, (long long*)out_pos, (long long)pos_offset);
+    HIP_TRY(hipGetLastError());
+    if (n_fixup) HIP_TRY(hipMemcpyAsync(n_fixup, fail + nq, sizeof(int), hipMemcpyDeviceToDevice, st));
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_bf16_rows(const float* x, int64_t rows, int64_t ld, int dim, uint16_t* out, int64_t ld_out,
+                                float* max_norm, void* stream) {
+    REQUIRE(dim >= 4 && dim % 4 == 0 && dim <= 2048, "dim=%d must be a multiple of 4 in [4,2048]", dim);
+    if (rows <= 0) return AMDREC_OK;
+    REQUIRE(x && out, "null pointer");
+    REQUIRE(ld >= dim && ld % 4 == 0 && ld_out >= dim && ld_out % 4 == 0, "leading dimensions must be >= dim and multiples of 4");
+    REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 8) == 0, "x must be 16-byte and out 8-byte aligned");
+    hipLaunchKernelGGL(bf16_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, (long long)rows, (long long)ld, dim, out,
+                       (long long)ld_out, max_norm);
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_flat_search_mixed_workspace(int64_t nq, int64_t nrows, int k, int dim, size_t* bytes) {
+    REQUIRE(bytes != nullptr, "bytes is null");
+    REQUIRE(nq >= 0 && nrows >= 0, "negative size");
+    REQUIRE(k >= 1 && k <= KMAX, "k=%d outside [1,%d]", k, KMAX);
+    REQUIRE(dim >= 8 && dim % 8 == 0 && dim <= 2048, "dim=%d must be a multiple of 8 in [8,2048]", dim);
+    SearchPlan pl;
+    make_plan(nq, nrows, k, pl, dim);
+    *bytes = pl.bytes;
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int64_t ld_corpus, int dim,
+                                        const uint16_t* corpus_bf16, int64_t ld_bf16, const float* max_norm,
+                                        const float* queries, int64_t nq, int64_t ld_queries, int k,
+                                        int64_t pos_offset, float* out_scores, int64_t* out_pos, void* workspace,
+                                        size_t workspace_bytes, int* n_fixup, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    REQUIRE(k >= 1 && k <= KMAX, "k=%d outside [1,%d]", k, KMAX);
+    REQUIRE(dim >= 8 && dim % 8 == 0 && dim <= 2048, "dim=%d must be a multiple of 8 in [8,2048]", dim);
+    REQUIRE(nrows >= 0 && nrows < (1ll << 31) - 1024, "nrows out of range");
+    REQUIRE(nq >= 0 && nq < (1ll << 24), "nq out of range");
+    if (nq == 0) return AMDREC_OK;
+    REQUIRE((nrows == 0 || (ld_corpus >= dim && ld_corpus % 4 == 0 && ld_bf16 >= dim && ld_bf16 % 8 == 0)) &&
+                ld_queries >= dim && ld_queries % 4 == 0,
+            "leading dimensions must be >= dim; fp32 multiples of 4, bf16 multiples of 8");
+    REQUIRE((corpus && corpus_bf16) || nrows == 0, "corpus is null");
+    REQUIRE(queries && out_scores && out_pos && max_norm, "null pointer");
+    REQUIRE(((uintptr_t)corpus % 16) == 0 && ((uintptr_t)corpus_bf16 % 16) == 0 && ((uintptr_t)queries % 16) == 0,
+            "corpus/queries must be 16-byte aligned");
+    SearchPlan pl;
+    make_plan(nq, nrows, k, pl, dim);
+    if (workspace_bytes < pl.bytes || workspace == nullptr)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", pl.bytes, workspace_bytes);
+    REQUIRE(((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
+    char* ws = reinterpret_cast<char*>(workspace);
+    int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
+    int* fail = reinterpret_cast<int*>(ws + pl.off_fail);
+    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));
+    HIP_TRY(hipMemsetAsync(fail, 0, (size_t)(nq + 1) * 4, st));
+
+    if (nrows > 0) {
+        uint16_t* q16 = reinterpret_cast<uint16_t*>(ws + pl.off_q16);
+        hipLaunchKernelGGL(bf16_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, queries, (long long)nq,
+                           (long long)ld_queries, dim, q16, (long long)dim, (float*)nullptr);
+        // the bf16 matrices as float matrices of dim/2 columns (gemm_core.hpp, Shape::BF16)
+        const float* X = reinterpret_cast<const float*>(corpus_bf16);
+        const float* Q = reinterpret_cast<const float*>(q16);
+        const long long ldx = ld_bf16 / 2, ldq = dim / 2;
+        const int dh = dim / 2;
+        hipError_t e;
+        if (nq > 64)       e = run_passes<Shape<2, 2, 4, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim);
+        else if (nq > 32)  e = run_passes<Shape<4, 1, 2, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim);
+        else               e = run_passes<Shape<4, 1, 2, 1, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim);
+        HIP_TRY(e);
+    }
+    const size_t fin_lds = (size_t)CAND_CAP * 8 + (size_t)dim * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_mixed_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_merge_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
+        attr_done = true;
+    }
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + pl.off_cand);
+    unsigned long long* fix = reinterpret_cast<unsigned long long*>(ws + pl.off_fix);
+    const float* tau = reinterpret_cast<const float*>(ws + pl.off_tau);
+    hipLaunchKernelGGL(finalize_mixed_kernel, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, cnt, CAND_CAP, k,
+                       (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries,
+                       (long long)ld_queries, fail, out_scores, (long long*)out_pos, (long long)pos_offset);
     hipLaunchKernelGGL(fixup_scan_kernel, dim3(pl.nslices, (unsigned)nq), dim3(512), 0, st, corpus,
                        (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, k,
                        pl.nslices, fix);

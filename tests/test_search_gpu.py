@@ -10,6 +10,18 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 
+_PREFILTER = "bf16"
+
+
+@pytest.fixture(params=["bf16", "fp32"], autouse=True)
+def prefilter(request):
+    """Every case runs through both engines: amdrec_flat_search_mixed (bf16 MFMA filter + fp32 re-score +
+    certificate, the default) and amdrec_flat_search (fp32 MFMA filter)."""
+    global _PREFILTER
+    _PREFILTER = request.param
+    yield request.param
+    _PREFILTER = "bf16"
+
 
 def _mk(n, d, seed):
     return synth.unit_corpus(n, d, seed=seed)
@@ -17,7 +29,8 @@ def _mk(n, d, seed):
 
 def _both(xb, xq, k, ad_ids=None):
     from amdrec.index import FAISSIndex
-    idx = FAISSIndex(xb.shape[1], index_type="Flat")
+    idx = FAISSIndex(xb.shape[1], index_type="Flat", prefilter=_PREFILTER)
+    assert idx._mixed == (_PREFILTER == "bf16" and xb.shape[1] % 8 == 0)
     ora = oracle.search.FlatIndex(xb.shape[1])
     idx.add(xb, ad_ids)
     ora.add(xb, ad_ids)
@@ -139,6 +152,49 @@ def test_padded_leading_dimension_and_device_api():
     oracle.search.check_topk(rD, rI + 1_000_000, D.cpu().numpy(), I.cpu().numpy(), tau=cases.TOPK_TAU,
                              score_tol=cases.SCORE_ATOL)
     assert int(nfix.item()) == 0
+
+
+def test_bf16_shadow_rows_and_max_norm():
+    """amdrec_bf16_rows == round-to-nearest-even bf16 (torch's cast), max_norm == largest row norm."""
+    from amdrec.index import FAISSIndex
+    rng = np.random.default_rng(21)
+    xb = (rng.standard_normal((5000, 72)) * rng.uniform(0.1, 3.0, (5000, 1))).astype(np.float32)
+    idx = FAISSIndex(72, index_type="Flat")
+    idx.add(xb[:3000])
+    idx.add(xb[3000:])                                              # growth + append keep the shadow in step
+    x = idx._xb[:5000]
+    assert torch.equal(idx._xb16[:5000].view(torch.int16), x.to(torch.bfloat16).view(torch.int16))
+    assert abs(idx._maxnorm.item() - x.norm(dim=1).max().item()) <= 1e-6
+
+
+def test_mixed_search_is_exact_on_unnormalised_rows_and_clustered_scores():
+    """The C entry point itself (no renormalisation): rows of very different norms, and a cluster of rows whose
+    exact scores differ by ~1e-5 around the k-th place - far below what bf16 resolves - must still come back as the
+    exact fp32 top-k (pruning margin + certificate), without the fix-up path on the well-spread case."""
+    from amdrec.index import flat_search_mixed
+    from amdrec import _lib
+    rng = np.random.default_rng(22)
+    n, nq, k, d = 60_000, 70, 100, 128
+    xb = (_mk(n, d, 23) * rng.uniform(0.2, 4.0, (n, 1))).astype(np.float32)
+    xq = (_mk(nq, d, 24) * rng.uniform(0.5, 2.0, (nq, 1))).astype(np.float32)
+    # 300 near-duplicates of query 0's direction: scores 1e-5 apart around ranks 1..300
+    xb[1000:1300] = xq[0] / np.linalg.norm(xq[0]) * 3.0 + rng.standard_normal((300, d)).astype(np.float32) * 1e-5
+    X = torch.from_numpy(xb).cuda()
+    X16 = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
+    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.amdrec_bf16_rows(_lib.ptr(X), n, d, d, _lib.ptr(X16), d, _lib.ptr(mx), _lib.stream_ptr(X.device)))
+    Q = torch.from_numpy(xq).cuda()
+    D = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    I = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    nfix = torch.zeros(1, dtype=torch.int32, device="cuda")
+    flat_search_mixed(X, X16, mx, n, Q, k, D, I, n_fixup=nfix)
+    rD, rI = oracle.search.flat_ip_search(xb, xq, k, dtype=np.float64)
+    # scores up to 8 in magnitude here: scale the absolute tolerances by the largest |score|
+    scale = float(np.abs(rD).max())
+    oracle.search.check_topk(rD, rI, D.cpu().numpy(), I.cpu().numpy(), tau=cases.TOPK_TAU * scale,
+                             score_tol=cases.SCORE_ATOL * scale)
+    assert int(nfix.item()) <= 1                                    # at most the clustered query
 
 
 def test_empty_and_error_paths():
