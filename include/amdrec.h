@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMDREC_ABI_VERSION 1
+#define AMDREC_ABI_VERSION 2
 #define AMDREC_MAX_K 2048
 
 int amdrec_abi_version(void);
@@ -174,6 +174,13 @@ typedef struct {
     const float* head_b2[AMDREC_MAX_TASKS];
     const float* head_w3[AMDREC_MAX_TASKS];   /* [head_h2] */
     const float* head_b3[AMDREC_MAX_TASKS];   /* [1] */
+    /* Optional candidate-side cache for the broadcast form: ad_proj_cache[a] = w_proj_ad . emb(ad_cat[a]) for every
+     * row of the resident ad-feature table (amdrec_ranker_project_ads; like the ad-tower embeddings it depends on
+     * the ad and the weights only, so it is computed once per index build).  When set (with w_proj_user/w_proj_ad)
+     * the ad half of the projection GEMM becomes a row gather: x0[r] = ad_proj_cache[ad row of r] + U[user of r],
+     * the same two addends in the same order as the uncached path (bit-identical). */
+    const float* ad_proj_cache;     /* [n_ad_rows][ld_ad_proj_cache] or NULL */
+    int64_t ld_ad_proj_cache;
 } amdrec_ranker_params;
 
 int amdrec_ranker_workspace(const amdrec_ranker_params* p /*host*/, int64_t rows, size_t* bytes /*host*/);
@@ -188,6 +195,12 @@ int amdrec_ranker_forward(const amdrec_ranker_params* p /*host*/, const int64_t*
                           const int64_t* ad_rowmap, int64_t rows, float* out_logits, int64_t ld_logits,
                           int* bad_index_flag, int64_t n_user_rows, int64_t n_ad_rows, void* workspace,
                           size_t workspace_bytes, void* stream);
+
+/* Fills the candidate-side cache described at amdrec_ranker_params.ad_proj_cache: out[a] = w_proj_ad . emb(ad_cat[a])
+ * (no bias; the user half carries it), a = 0..n_ads-1.  workspace: >= 4*d_model + 256 bytes. */
+int amdrec_ranker_project_ads(const amdrec_ranker_params* p /*host*/, const int64_t* ad_cat, int64_t n_ads,
+                              float* out /*[n_ads][ld_out]*/, int64_t ld_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* faiss.normalize_L2 (faiss_retrieval.py:115, :147): every row scaled by 1/||row||_2, rows of
  * zero norm left as they are.  out may alias in.  dim % 4 == 0. */

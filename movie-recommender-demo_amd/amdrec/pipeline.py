@@ -79,7 +79,8 @@ class AdRecommenderInference:
                  two_tower_model: Optional[TwoTowerModel] = None,
                  transformer_ranker: Optional[TransformerRanker] = None,
                  faiss_index: Optional[FAISSIndex] = None, ad_features=None,
-                 preprocessor: Optional[Preprocessor] = None, verbose: bool = False):
+                 preprocessor: Optional[Preprocessor] = None, verbose: bool = False,
+                 cache_ad_projection: bool = True):
         """Either ``model_dir`` (files below) or the components directly.
         model_dir: preprocessor.json, two_tower_{best,final}.pt, transformer_ranker_{best,final}.pt,
         faiss_index.bin (+ .metadata) in this build's format, ad_features.npy [N, 20]."""
@@ -87,6 +88,9 @@ class AdRecommenderInference:
         if self.device.type != "cuda":
             raise _lib.AmdrecError("AdRecommenderInference needs a HIP device (no CPU fallback)")
         self.verbose = verbose
+        # candidate-side cache of the ranker's ad-half projection (TransformerRanker.cache_ad_projection):
+        # N x d_model fp32 next to the ad-feature table, rebuilt when the weights change
+        self.cache_ad_projection = cache_ad_projection
         _lib.load()
         if model_dir is not None:
             d = Path(model_dir)
@@ -165,6 +169,8 @@ class AdRecommenderInference:
     def _stage2(self, uc, un, cand_pos, top_k, check_indices, ids_are_positions=False):
         lib = _lib.load()
         B, stage1_k = cand_pos.shape
+        if self.cache_ad_projection:
+            self.transformer_ranker.ensure_ad_cache(self.ad_features)
         tasks, logits = self.transformer_ranker.score_candidates(uc, un, cand_pos, self.ad_features,  # :241-255
                                                                  check_indices=check_indices, raw=True)
         ad_ids = torch.empty((B, top_k), dtype=torch.int64, device=uc.device)
@@ -311,7 +317,7 @@ class GraphedRecommender:
         # makes the graph stale (documented) but can never leave it with dangling pointers
         idx = rec.faiss_index
         self._pinned = (rec.two_tower_model.user_tower._packed, rec.transformer_ranker._packed, idx._xb, idx._ids,
-                        idx._xb16, idx._maxnorm, rec.ad_features, getattr(idx, "_ivf", None) and idx._ivf._lists)
+                        idx._xb16, idx._maxnorm, rec.ad_features, rec.transformer_ranker._ad_cache, getattr(idx, "_ivf", None) and idx._ivf._lists)
 
     @torch.no_grad()
     def __call__(self, user_categorical: torch.Tensor, user_numerical: torch.Tensor):

@@ -77,6 +77,7 @@ class TransformerRanker(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self._user_names, self._ad_names, self._n_num = list(user_feature_dims), list(ad_feature_dims), numerical_dim
         self._packed = None
+        self._ad_cache = None
         # W_ov = W_o W_v pre-multiplied on the host (exact algebra at seq_len 1; set False to run the two
         # GEMMs in the reference's order)
         self.fuse_attention = True
@@ -84,6 +85,46 @@ class TransformerRanker(nn.Module):
     # -- packing ----------------------------------------------------------------------
     def invalidate(self):
         self._packed = None
+        self._ad_cache = None
+
+    def cache_ad_projection(self, ad_table: Optional[torch.Tensor]):
+        """Candidate-side cache for ``score_candidates``: the ad half of the feature projection,
+        W_proj[:, ad columns] . emb(ad_table[a]), for every row of the resident ad-feature table
+        ([N, d_model] fp32, N * 1 KB of HBM at d_model 256).  Like the ad-tower embeddings in the index it depends
+        on the ad and the weights only; with it stage 2 replaces the widest-K GEMM of the ranker by a row gather and
+        returns bit-identical logits.  ``None`` drops the cache.  Re-packing the weights (load_state_dict, a
+        parameter update) drops it too; ``score_candidates`` uses it only for the very table it was built from."""
+        self._ad_cache = None
+        if ad_table is None:
+            return None
+        table = _lib.require_gpu(ad_table, "ad_table", torch.int64)
+        if not table.is_contiguous() or table.dim() != 2 or table.shape[1] != len(self._ad_names):
+            raise ValueError("ad_table must be a contiguous [N, n_ad_feat] int64 tensor")
+        dev = table.device
+        params, _ = self._pack(dev)
+        if not params.w_proj_ad:
+            return None                                     # no ad features / no split projection
+        lib = _lib.load()
+        out = torch.empty((table.shape[0], self.d_model), dtype=torch.float32, device=dev)
+        ws = _lib.WORKSPACE.get(4 * self.d_model + 256, dev)
+        _lib.check(lib.amdrec_ranker_project_ads(_lib.C.byref(params), _lib.ptr(table), table.shape[0], _lib.ptr(out),
+                                                 out.stride(0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+        self._ad_cache = (self._packed[0], table.data_ptr(), tuple(table.shape), table._version, out)
+        return out
+
+    def ensure_ad_cache(self, ad_table):
+        """Build the cache for ``ad_table`` unless a valid one exists (weights or table changed -> rebuilt)."""
+        self._pack(ad_table.device)
+        if self._cache_for(ad_table) is None:
+            self.cache_ad_projection(ad_table)
+
+    def _cache_for(self, table):
+        c = getattr(self, "_ad_cache", None)
+        if c is None or self._packed is None:
+            return None
+        if c[0] != self._packed[0] or c[1] != table.data_ptr() or c[2] != tuple(table.shape) or c[3] != table._version:
+            return None
+        return c[4]
 
     def _pack(self, device):
         key = (str(device), self.fuse_attention, tuple(p._version for p in self.parameters()))
@@ -99,11 +140,15 @@ class TransformerRanker(nn.Module):
         return r
 
     # -- forward ----------------------------------------------------------------------
-    def _run(self, user_cat, numerical, user_rowdiv, ad_cat, ad_rowmap, rows, check_indices=True, raw=False):
+    def _run(self, user_cat, numerical, user_rowdiv, ad_cat, ad_rowmap, rows, check_indices=True, raw=False,
+             use_cache=False):
         if self.training:
             raise NotImplementedError("the HIP forward implements eval() semantics only; call .eval()")
         dev = ad_cat.device
         params, tasks = self._pack(dev)
+        cache = self._cache_for(ad_cat) if use_cache else None
+        params.ad_proj_cache = cache.data_ptr() if cache is not None else None
+        params.ld_ad_proj_cache = cache.stride(0) if cache is not None else 0
         lib = _lib.load()
         logits = torch.empty((len(tasks), rows), dtype=torch.float32, device=dev)
         if rows == 0:
@@ -146,7 +191,7 @@ class TransformerRanker(nn.Module):
         U, k = cand.shape
         if uc.shape[0] != U or nm.shape[0] != U:
             raise ValueError("one user row per candidate list expected")
-        return self._run(uc, nm, k, table, cand.view(-1), U * k, check_indices, raw)
+        return self._run(uc, nm, k, table, cand.view(-1), U * k, check_indices, raw, use_cache=True)
 
     def compute_loss(self, *a, **k):
         raise NotImplementedError("training (transformer_ranker.py:382-415) is outside the MI355X hot path")

@@ -40,7 +40,8 @@ class RankerParams(C.Structure):
                 ("cross_wt", _FP * MAX_LAYERS), ("cross_b", _FP * MAX_LAYERS),
                 ("head_w1", _FP), ("head_b1", _FP),
                 ("head_w2", _FP * MAX_TASKS), ("head_b2", _FP * MAX_TASKS),
-                ("head_w3", _FP * MAX_TASKS), ("head_b3", _FP * MAX_TASKS)]
+                ("head_w3", _FP * MAX_TASKS), ("head_b3", _FP * MAX_TASKS),
+                ("ad_proj_cache", _FP), ("ld_ad_proj_cache", C.c_int64)]
 
 
 def _np64(t):

@@ -621,6 +621,54 @@ extern "C" int amdrec_ranker_workspace(const amdrec_ranker_params* p, int64_t ro
     return AMDREC_OK;
 }
 
+// x0[r] = ad_proj_cache[ad row of r] + U[user of r]  (the cached form of the EpiRowBiasT projection: same addends,
+// same order).  One wave per row.
+__global__ __launch_bounds__(256) void proj_gather_kernel(const float* cache, long long ldc, long long n_cache,
+                                                          const long long* rowmap, long long row_base, const float* U,
+                                                          int dm, int rowdiv, float* X, long long m) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= m) return;
+    const long long gr = row_base + r;
+    long long a = rowmap ? rowmap[gr] : gr;
+    a = a < 0 ? 0 : (a >= n_cache ? n_cache - 1 : a);        // clamped like the gather loader (reported separately)
+    const f32x4* cp = reinterpret_cast<const f32x4*>(cache + a * ldc);
+    const f32x4* up = reinterpret_cast<const f32x4*>(U + (gr / rowdiv) * dm);
+    f32x4* xp = reinterpret_cast<f32x4*>(X + r * dm);
+    for (int c = lane; c < (dm >> 2); c += 64) {
+        const f32x4 a4 = cp[c], u4 = up[c];
+        xp[c] = f32x4{a4[0] + u4[0], a4[1] + u4[1], a4[2] + u4[2], a4[3] + u4[3]};
+    }
+}
+
+extern "C" int amdrec_ranker_project_ads(const amdrec_ranker_params* p, const int64_t* ad_cat, int64_t n_ads,
+                                         float* out, int64_t ld_out, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+    int rc = ranker_check(p);
+    if (rc) return rc;
+    if (n_ads <= 0) return AMDREC_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int dm = p->d_model, F0 = p->n_user_feat, F = p->n_user_feat + p->n_ad_feat;
+    REQUIRE(p->w_proj_ad && p->n_ad_feat > 0, "params carry no split projection (w_proj_ad)");
+    REQUIRE(ad_cat && out, "null pointer");
+    REQUIRE(ld_out >= dm && ld_out % 4 == 0 && ((uintptr_t)out % 16) == 0, "bad output layout");
+    REQUIRE(n_ads < (1ll << 31) - 1024, "n_ads out of range");
+    const size_t need = align_up((size_t)dm * 4, 256);
+    if (!workspace || workspace_bytes < need)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    float* zero = reinterpret_cast<float*>(workspace);
+    HIP_TRY(hipMemsetAsync(zero, 0, (size_t)dm * 4, st));
+    EmbConcatRows ga{};
+    ga.tables = p->tables; ga.off = p->table_off + F0; ga.card = p->cards + F0;
+    ga.cat0 = nullptr; ga.cat1 = (const long long*)ad_cat; ga.rowmap1 = nullptr; ga.num = nullptr;
+    ga.row_base = 0; ga.rows = n_ads; ga.rows1 = n_ads; ga.F = F - F0; ga.F0 = 0; ga.E = p->emb_dim;
+    ga.eshift = ilog2(p->emb_dim); ga.n_num = 0; ga.cat0_rowdiv = 1;
+    // the same GEMM (shape, K order) as the uncached candidate half, with an all-zero "user row"
+    HIP_TRY(linear_wide<EpiRowBiasT>(p->w_proj_ad, p->ldw_proj_ad, dm, ga, n_ads, st, (F - F0) * p->emb_dim,
+                                     (const float*)zero, out, (long long)ld_out, n_ads, 0ll, 0x7fffffff, dm));
+    return AMDREC_OK;
+}
+
 extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_t* user_cat, const float* numerical,
                                      int64_t user_rowdiv, const int64_t* ad_cat, const int64_t* ad_rowmap,
                                      int64_t rows, float* out_logits, int64_t ld_logits, int* bad_index_flag,
@@ -686,7 +734,11 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         g.rows1 = n_ad_rows > 0 ? n_ad_rows : 1;
         g.rows = m; g.F = F; g.F0 = F0; g.E = p->emb_dim; g.eshift = ilog2(p->emb_dim);
         g.n_num = p->n_num; g.cat0_rowdiv = (int)user_rowdiv;
-        if (hoist) {
+        if (hoist && p->ad_proj_cache) {
+            hipLaunchKernelGGL(proj_gather_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, p->ad_proj_cache,
+                               (long long)p->ld_ad_proj_cache, (long long)(n_ad_rows > 0 ? n_ad_rows : 1),
+                               (const long long*)ad_rowmap, r0, (const float*)U, dm, (int)user_rowdiv, X, m);
+        } else if (hoist) {
             // candidate half: ad embeddings only (K = n_ad_feat * emb_dim), plus the user's row of U
             EmbConcatRows ga = g;
             ga.off = p->table_off + F0; ga.card = p->cards + F0;

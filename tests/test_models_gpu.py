@@ -128,6 +128,32 @@ def test_ranker_score_candidates_broadcast_and_gather():
         assert ok, (t, err)
 
 
+def test_ranker_ad_projection_cache_is_bit_identical_and_invalidates():
+    """cache_ad_projection: the cached (row-gather) form of the candidate half of the projection returns exactly the
+    logits of the GEMM form; a weight update or another table drops it (the GEMM form runs again)."""
+    m, sd, (user, ad, nnum), _ = _ranker("demo", "scaled")
+    U, k, N = 9, 500, 20_000
+    uc, un = synth.user_batch(user, nnum, U, seed=19)
+    table = _cu(synth.ad_features(ad, N, seed=20))
+    cand = _cu(np.random.default_rng(21).integers(0, N, (U, k)))
+    base = m.score_candidates(_cu(uc), _cu(un), cand, table)
+    cache = m.cache_ad_projection(table)
+    assert cache.shape == (N, 256) and m._cache_for(table) is cache
+    hit = m.score_candidates(_cu(uc), _cu(un), cand, table)
+    for t in base:
+        assert torch.equal(base[t], hit[t]), t
+    other = table.clone()
+    assert m._cache_for(other) is None                                   # not the table it was built from
+    with torch.no_grad():
+        m.feature_projection.weight.mul_(1.5)                            # weight update -> repack -> cache dropped
+    upd = m.score_candidates(_cu(uc), _cu(un), cand, table)
+    assert m._cache_for(table) is None and not torch.equal(upd["ctr"], base["ctr"])
+    m.ensure_ad_cache(table)
+    again = m.score_candidates(_cu(uc), _cu(un), cand, table)
+    for t in upd:
+        assert torch.equal(upd[t], again[t]), t
+
+
 def test_bad_index_raises_like_torch_and_train_mode_refused():
     m, sd, (user, ad, nnum), _ = _two_tower("demo")
     uc, un = synth.user_batch(user, nnum, 4, seed=1)
