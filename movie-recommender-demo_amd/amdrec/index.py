@@ -242,7 +242,7 @@ class FAISSIndex:
             # id_map[-1] in the reference (:159) - reproduce that too
             if return_positions:
                 return pos, scores
-            if self._n:
+            if self._n and (k > self._n or self.index_type == "IVF"):   # only then can a slot be unfilled
                 pos = torch.where(pos < 0, pos + self._n, pos)
             return pos, scores
         lib = _lib.load()

@@ -179,7 +179,8 @@ class AdRecommenderInference:
         if ids_are_positions:
             cand_ids = cand_pos
         elif idx._identity:
-            cand_ids = torch.where(cand_pos < 0, cand_pos + idx._n, cand_pos) if idx._n else cand_pos
+            unfilled = idx._n and (stage1_k > idx._n or idx.index_type == "IVF")     # else every slot is filled
+            cand_ids = torch.where(cand_pos < 0, cand_pos + idx._n, cand_pos) if unfilled else cand_pos
         else:
             cand_ids = torch.empty_like(cand_pos)
             _lib.check(lib.amdrec_remap_ids(_lib.ptr(cand_pos), _lib.ptr(idx._ids), idx._n, _lib.ptr(cand_ids),

@@ -29,22 +29,28 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const float* xs, long lon
     __syncthreads();
     unsigned long long* dst = keys + (long long)q * pool_ld + base[(long long)q * nprobe + p];
     const int d4 = d >> 2;
-    constexpr int NW = 4, U = 4;
+    constexpr int NW = 4, U = 8;
     for (long long row0 = r0; row0 < r1; row0 += NW * U) {
         float part[U];
+        const f32x4* xr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long r = row0 + w * U + u;
-            float a = 0.f;
-            if (r < r1) {
-                const f32x4* xr = reinterpret_cast<const f32x4*>(xs + r * ld);
-                for (int c = lane; c < d4; c += 64) {
-                    const f32x4 x = xr[c];
-                    const f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * c]);
-                    a += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
-                }
-            }
-            part[u] = a;
+            long long r = row0 + w * U + u;
+            r = r < r1 ? r : r1 - 1;                           // clamped: branch-free loads, result dropped below
+            xr[u] = reinterpret_cast<const f32x4*>(xs + r * ld);
+            part[u] = 0.f;
+        }
+        // column chunk outermost so that the U row loads of a chunk are in flight together (with the row loop
+        // outside, each row's load had to return before the next row's was issued)
+        for (int c = lane; c < d4; c += 64) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * c]);
+            f32x4 x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = xr[u][c];
+#pragma unroll
+            for (int u = 0; u < U; ++u)        // explicit fma chain: the same rounding sequence in every slot u
+                part[u] = __builtin_fmaf(x[u][3], y[3], __builtin_fmaf(x[u][2], y[2], __builtin_fmaf(x[u][1], y[1],
+                                         __builtin_fmaf(x[u][0], y[0], part[u]))));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

@@ -4,7 +4,7 @@
 // Algorithm ("threshold-prefiltered exact top-k"), all on device, no host sync:
 //   1. sample pass : scores of every query against an evenly spaced subset of corpus tiles
 //                    (fp32 MFMA GEMM, dense store)                     ~3 % of the corpus
-//   2. threshold   : per query tau_q ~ the r-th largest sample score (r-th largest of 256 per-thread
+//   2. threshold   : per query tau_q ~ the r-th largest sample score (r-th largest of 256 per-group
 //                    maxima); the expected number of corpus rows with score >= tau_q is ~max(2k, k+900)
 //   3. filter pass : fp32 MFMA GEMM over the whole corpus; the epilogue appends
 //                    (score, row) keys with score >= tau_q to a per-query candidate list
@@ -26,6 +26,7 @@
 //   * and certifies: every row outside the list has approx < tau, i.e. exact < tau + eps; if the k-th re-scored
 //     value is >= tau + eps nothing outside can enter the top-k.  A query that fails the certificate (or the
 //     count test) goes to the same exact fp32 fix-up scan as before.
+#include <type_traits>
 #include "gemm_core.hpp"
 #include "topk_utils.hpp"
 #include "../../include/amdrec.h"
@@ -74,23 +75,38 @@ struct EpiStoreScores {
     }
 };
 
+// Filter epilogue: keys of (score >= tau_q) elements are appended to the per-query candidate lists.  A returning
+// global atomic per hit made the epilogue a chain of ~10 dependent 1-2 us round trips per wave (measured: the bf16
+// filter spent more time here than in its K loop), so hits are first collected in an LDS list (LDS atomics), and after
+// one barrier each hit is appended by its own lane: the global atomics of a block go out together.  Hits beyond the
+// LDS list (threshold-less small corpora, adversarial data) take the direct path.
+constexpr int HIT_CAP = 2048;
 struct EpiFilter {
     static constexpr const char* name = "search_filter";
     static constexpr double out_bytes_per_elem = 0.0;
-    static constexpr size_t lds_bytes(int) { return 0; }
+    static constexpr size_t lds_bytes(int) { return 16 + (size_t)HIT_CAP * 12; }
     const float* tau;            // [nq]
     unsigned long long* cand;    // [nq][cap]
     int* cnt;                    // [nq]
     int cap, nq;
     long long nrows;
+    __device__ __forceinline__ void append(int q, unsigned long long key) const {
+        const int pos = atomicAdd(&cnt[q], 1);
+        if (pos < cap) cand[(long long)q * cap + pos] = key;
+    }
     template <class A>
-    __device__ void operator()(A& acc, float*) const {
+    __device__ void operator()(A& acc, float* smem) const {
         constexpr int TP = A::TP, TQ = A::TQ;
         const int lane = threadIdx.x & 63;
+        int* lcount = reinterpret_cast<int*>(smem);
+        unsigned long long* hkey = reinterpret_cast<unsigned long long*>(smem + 4);      // 16-byte offset
+        int* hq = reinterpret_cast<int*>(hkey + HIT_CAP);
+        if (threadIdx.x == 0) *lcount = 0;          // the K loop's last barrier released the staging tiles
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
             int q = acc.q(j, lane);
-            float t = (q < nq) ? tau[q] : INFINITY;
+            float t = (q < nq) ? tau[q] : __builtin_nanf("");      // NaN: no score compares >= it
 #pragma unroll
             for (int i = 0; i < TP; ++i)
 #pragma unroll
@@ -98,36 +114,51 @@ struct EpiFilter {
                     float s = acc.v[i][j][r];
                     int p = acc.p(i, r, lane);
                     if (s >= t && p < nrows) {
-                        int pos = atomicAdd(&cnt[q], 1);
-                        if (pos < cap) cand[(long long)q * cap + pos] = make_key(s, (uint32_t)p);
+                        const unsigned long long key = make_key(s, (uint32_t)p);
+                        const int slot = atomicAdd(lcount, 1);
+                        if (slot < HIT_CAP) { hkey[slot] = key; hq[slot] = q; }
+                        else append(q, key);
                     }
                 }
         }
+        __syncthreads();
+        const int n = *lcount < HIT_CAP ? *lcount : HIT_CAP;
+        for (int h = threadIdx.x; h < n; h += blockDim.x) append(hq[h], hkey[h]);
     }
 };
 
 // Threshold from the sample: tau[q] only has to BOUND the candidate count (any value with
 // k <= #{score >= tau} <= capacity gives the exact result), so instead of an exact radix select of the
-// r-th largest sample score (3 histogram passes, measured 157 us per launch) each of the 256 threads
+// r-th largest sample score (3 histogram passes, measured 157 us per launch) each of 256 thread groups
 // takes the maximum of its strided share of the sample and tau is the r-th largest of those 256 maxima:
 // one coalesced pass.  The true sample rank of that value is >= r (two of the top values may share a
-// thread), i.e. the threshold errs on the side of MORE candidates: r..~1.3r, far inside the capacity.
+// group; expected r + r^2/512), i.e. the threshold errs on the side of MORE candidates, far inside the capacity.
 // NaN counts as lowest; fewer than r finite maxima -> -inf.
-__global__ __launch_bounds__(256) void sample_threshold_kernel(const float* S, long long ld, long long n, int r,
-                                                               float* tau) {
-    __shared__ float mx[256];
+constexpr int THR_NT = 1024;
+__global__ __launch_bounds__(THR_NT) void sample_threshold_kernel(const float* S, long long ld, long long n, int r,
+                                                                  float* tau) {
+    __shared__ float mx[THR_NT];
     const int q = blockIdx.x, tid = threadIdx.x;
     const float* row = S + (long long)q * ld;
     float m = -INFINITY;
-    for (long long i = tid; i < n; i += 256) {
-        const float v = row[i];
-        m = (v > m) ? v : m;          // NaN compares false: ignored
+    for (long long i = 4ll * tid; i < n; i += 4 * THR_NT) {      // n % 256 == 0, rows 16-byte aligned
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = (v[e] > m) ? v[e] : m;   // NaN compares false: ignored
     }
     mx[tid] = m;
     __syncthreads();
+    // 256 group maxima (each over 4 threads' shares), ranked by the first 4 waves
+    __shared__ float gm[256];
+    if (tid < 256) {
+        m = fmaxf(fmaxf(mx[tid], mx[tid + 256]), fmaxf(mx[tid + 512], mx[tid + 768]));
+        gm[tid] = m;
+    }
+    __syncthreads();
+    if (tid >= 256) return;
     int rank = 0;                     // number of maxima ahead of mine (ties: lower thread first)
     for (int j = 0; j < 256; ++j) {
-        const float o = mx[j];
+        const float o = gm[j];
         rank += (o > m) || (o == m && j < tid);
     }
     if (rank == r - 1) tau[q] = m;    // exactly one thread has this rank (r <= 256)
@@ -164,7 +195,7 @@ __global__ __launch_bounds__(512) void fixup_scan_kernel(const float* X, long lo
     const int q = blockIdx.y, s = blockIdx.x;
     if (!fail[q]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    constexpr int NW = 8, U = 4;
+    constexpr int NW = 8, U = 8;
     for (int i = tid; i < d; i += 512) qv[i] = Q[(long long)q * ldq + i];
     if (tid == 0) { thr = 0ull; count = 0; }
     __syncthreads();
@@ -185,19 +216,24 @@ __global__ __launch_bounds__(512) void fixup_scan_kernel(const float* X, long lo
     };
     for (long long row0 = begin; row0 < end; row0 += NW * U) {
         float part[U];
+        const f32x4* xr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             long long r = row0 + w * U + u;
-            float a = 0.f;
-            if (r < end) {
-                const f32x4* xr = reinterpret_cast<const f32x4*>(X + r * ldx);
-                for (int c = lane; c < d4; c += 64) {
-                    f32x4 x = xr[c];
-                    f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * c]);
-                    a += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
-                }
-            }
-            part[u] = a;
+            r = r < end ? r : end - 1;                         // clamped: branch-free loads, result dropped below
+            xr[u] = reinterpret_cast<const f32x4*>(X + r * ldx);
+            part[u] = 0.f;
+        }
+        // column chunk outermost so that the U row loads of a chunk are in flight together
+        for (int c = lane; c < d4; c += 64) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * c]);
+            f32x4 x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = xr[u][c];
+#pragma unroll
+            for (int u = 0; u < U; ++u)        // explicit fma chain: the same rounding sequence in every slot u
+                part[u] = __builtin_fmaf(x[u][3], y[3], __builtin_fmaf(x[u][2], y[2], __builtin_fmaf(x[u][1], y[1],
+                                         __builtin_fmaf(x[u][0], y[0], part[u]))));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -267,6 +303,245 @@ __global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, con
     write_result(keys, total < k ? total : k, k, q, outD, outI, 0);
 }
 
+// ---- streaming bf16 filter (the mixed search's corpus pass for dim in {32, 64, 128, 256}) ---------------------
+// The generic GEMM tiles re-stage the query tile for every corpus tile and prefetch one 128-byte K-step ahead: with
+// K = 256 bf16 a tile is only four K-steps of 0.4 us of MFMA each, far less than the HBM latency, and the pass ran
+// latency-bound at ~14 % of HBM.  Here the roles are fixed for the whole launch instead:
+//  * one 8-wave workgroup per CU; wave w owns queries [64 w, 64 w + 64) of the block's 512-query group and keeps
+//    their bf16 fragments for the WHOLE K extent in registers (2 x KS x 4 VGPRs = 128 at dim 256): queries are read
+//    once per launch, never staged through LDS;
+//  * the corpus streams through a two-deep LDS ring of 128-row full-K tiles (64 KB at dim 256) filled by LDS-DMA
+//    (global_load_lds, 16 B per lane, source-side XOR swizzle so the fragment reads are conflict-free); the next tile
+//    is in flight during the MFMAs on the current one - one barrier per tile;
+//  * every wave multiplies the same 32 corpus rows at a time (one A fragment per k16 step, read from LDS four steps
+//    ahead) with its own 64 queries: 2 accumulator tiles, v_mfma_f32_32x32x16_bf16, then compares against tau_q;
+//  * hits go to a wave-private LDS list without atomics (ballot + lane prefix; the wave's count lives in an SGPR);
+//    the wave appends them to the global candidate lists one tile later: the returning global atomics are issued
+//    before the next tile's MFMAs and their results consumed after, so their latency is never exposed.
+// Each corpus byte is read from HBM once per 512 queries; waves whose queries lie beyond nq skip their MFMAs, so a
+// small batch runs at the HBM rate and a full one at the bf16 MFMA rate.
+constexpr int SCAN_ROWS = 128;          // corpus rows per LDS tile
+constexpr int SCAN_WHITS = 128;         // hit-list entries per wave and tile (expected ~11; overflow -> direct append)
+constexpr int SCAN_QGROUP = 512;        // queries per workgroup (8 waves x 64)
+constexpr int SCAN_HIT_BYTES = 2 * 8 * SCAN_WHITS * 12;   // [2 lists][8 waves] x {keys u64[SCAN_WHITS], q int[SCAN_WHITS]}
+
+// LDS stores of the hit list, hidden from the compiler: it orders every LDS write it can see after the LDS-DMA in
+// flight (s_waitcnt vmcnt(0)), which would stall each wave on the next tile's loads at its first hit.  The hit lists
+// and the tile ring are disjoint and a wave's LDS operations execute in order, so no wait is needed.
+__device__ __forceinline__ void lds_store_hit_opaque(uint32_t key_addr, unsigned long long key, uint32_t q_addr, int q) {
+    asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(key_addr), "v"(key), "v"(q_addr), "v"(q) : "memory");
+}
+
+template <int KS>                       // KS = dim / 16 in {2, 4, 8, 16}
+__global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __restrict__ X16, long long ld16,
+                                                             long long nrows, const uint16_t* __restrict__ Q16, int nq,
+                                                             const float* __restrict__ tau, unsigned long long* cand,
+                                                             int* cnt, int cap, int nx) {
+    constexpr int CPR = 2 * KS;                                  // 16-byte chunks per row
+    constexpr int FM = CPR < 16 ? CPR - 1 : 15;                  // swizzle mask
+    constexpr int FS = CPR >= 16 ? 0 : (CPR == 8 ? 1 : 2);       // swizzle row shift
+    constexpr int TILE_CHUNKS = SCAN_ROWS * CPR;
+    constexpr int PASSES = TILE_CHUNKS / 512;
+    constexpr int AHEAD = KS < 4 ? KS : 4;                       // A fragments read ahead of their MFMA
+    static_assert(TILE_CHUNKS % 512 == 0, "tile must fill whole DMA passes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* tilebuf = lds;                                                  // [2][TILE_CHUNKS * 16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                        // scalar: wave-uniform branches below
+    unsigned char* hitbase = lds + 2 * TILE_CHUNKS * 16 + w * (SCAN_WHITS * 12);   // this wave's list 0; list 1 is
+    constexpr int LIST_STRIDE = 8 * SCAN_WHITS * 12;                               // LIST_STRIDE bytes further
+    const int frow = lane & 31, fh = lane >> 5;
+    const int bx = blockIdx.x % nx, by = blockIdx.x / nx;
+    const int q0 = by * SCAN_QGROUP + w * 64;
+    const bool active = q0 < nq;
+    const bool second = q0 + 32 < nq;                                              // second query tile has real queries
+    const int ntiles = (int)((nrows + SCAN_ROWS - 1) / SCAN_ROWS);
+    const int nrows_i = (int)nrows;                                                // < 2^31 (checked by the entry point)
+
+    // query fragments + thresholds (clamped rows; columns >= nq get tau = NaN)
+    bf16x8 qf[2][KS];
+    float tq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = q0 + j * 32 + frow;
+        const int qc = q < nq ? q : nq - 1;
+        tq[j] = (q < nq) ? tau[q] : __builtin_nanf("");            // NaN: no score compares >= it
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_)
+            qf[j][s_] = *reinterpret_cast<const bf16x8*>(Q16 + (long long)qc * (16 * KS) + (2 * s_ + fh) * 8);
+    }
+
+    // DMA lane map: LDS chunk slot L = u * 512 + tid of pass u -> row u * RPP + tid / CPR, slot tid % CPR; the source
+    // chunk (slot ^ swizzle(row)) does not depend on u (RPP is a multiple of the swizzle period), so a lane's source
+    // address is a per-lane byte offset plus a scalar per (tile, pass)
+    constexpr int RPP = 512 / CPR;                                 // rows per DMA pass
+    const int drow = tid / CPR;
+    const uint32_t lane_off = (uint32_t)(drow * (int)ld16 * 2 + (((tid % CPR) ^ ((drow >> FS) & FM)) * 16));
+    auto dma = [&](int tile, int buf) {
+        const long long row0 = (long long)tile * SCAN_ROWS;
+        unsigned char* lbase = tilebuf + (size_t)buf * TILE_CHUNKS * 16 + (size_t)(w * 64) * 16;           // wave-uniform
+        if (row0 + SCAN_ROWS <= nrows) {
+            const unsigned char* gb = reinterpret_cast<const unsigned char*>(X16) + row0 * ld16 * 2;
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u) {
+                const unsigned char* g = gb + (long long)u * RPP * ld16 * 2 + lane_off;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(lbase + (size_t)u * 512 * 16),
+                                                 16, 0, 0);
+            }
+        } else {                                                   // last tile: rows past the end are clamped
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u) {
+                long long r = row0 + u * RPP + drow;
+                r = r < nrows ? r : nrows - 1;
+                const unsigned char* g = reinterpret_cast<const unsigned char*>(X16) + r * ld16 * 2 +
+                                         (((tid % CPR) ^ ((drow >> FS) & FM)) * 16);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(lbase + (size_t)u * 512 * 16),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    auto append = [&](int q, unsigned long long key) {
+        const int pos = atomicAdd(&cnt[q], 1);
+        if (pos < cap) cand[(long long)q * cap + pos] = key;
+    };
+    // 32 corpus rows (LDS image at `lb`, fragment k-offset swizzle G) x NJ query tiles: K loop with the A fragments
+    // read AHEAD steps before their MFMA, then the threshold scan.  wcount = this wave's hits so far in this tile.
+    auto quarter = [&](auto nj_tag, auto full_tag, const unsigned char* lb, int G, int prow, uint32_t list_addr,
+                       int& wcount) {
+        constexpr int NJ = decltype(nj_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;           // every row of the tile is a corpus row
+        f32x16 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        bf16x8 a[AHEAD];
+#pragma unroll
+        for (int s_ = 0; s_ < AHEAD; ++s_) a[s_] = *reinterpret_cast<const bf16x8*>(lb + ((32 * s_) ^ G));
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            const bf16x8 cur = a[s_ % AHEAD];
+            if (s_ + AHEAD < KS) a[s_ % AHEAD] = *reinterpret_cast<const bf16x8*>(lb + ((32 * (s_ + AHEAD)) ^ G));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, qf[j][s_], acc[j], 0, 0, 0);
+        }
+        // Threshold scan.  A hit is rare per element (~1.4e-3) but a taken branch per element costs more than the
+        // MFMAs it follows, so four elements share one test (their maximum; NaN never wins) and the per-element code
+        // is out of line.
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float m4 = fmaxf(fmaxf(acc[j][4 * g], acc[j][4 * g + 1]), fmaxf(acc[j][4 * g + 2], acc[j][4 * g + 3]));
+                if (__builtin_expect(__ballot(m4 >= tq[j]) == 0ull, 1)) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sc = acc[j][4 * g + e];
+                    const int p = prow + e + 8 * g;
+                    const bool hit = sc >= tq[j] && (FULL || p < nrows_i);
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask) {                                    // wave-uniform
+                        if (hit) {
+                            const int q = q0 + j * 32 + frow;
+                            const unsigned long long key = make_key(sc, (uint32_t)p);
+                            const int slot = wcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            if (slot < SCAN_WHITS)
+                                lds_store_hit_opaque(list_addr + slot * 8, key, list_addr + SCAN_WHITS * 8 + slot * 4, q);
+                            else append(q, key);
+                        }
+                        wcount += __builtin_popcountll(mask);
+                    }
+                }
+            }
+    };
+
+    int t = bx;
+    if (t < ntiles) dma(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                               // first tile landed
+    int it = 0, wprev = 0;                                         // wprev: hits of the previous tile awaiting their append
+    for (; t < ntiles; t += nx, ++it) {
+        const int buf = it & 1;
+        // previous tile's hits, first 64: issue the position atomics now, consume them after this tile's MFMAs
+        const unsigned char* lprev = hitbase + (buf ^ 1) * LIST_STRIDE;
+        const int npend = wprev < SCAN_WHITS ? wprev : SCAN_WHITS;
+        int pos = 0;
+        if (lane < npend) pos = atomicAdd(&cnt[reinterpret_cast<const int*>(lprev + SCAN_WHITS * 8)[lane]], 1);
+        for (int h = 64 + lane; h < npend; h += 64)                // more than 64 hits in one tile: rare
+            append(reinterpret_cast<const int*>(lprev + SCAN_WHITS * 8)[h],
+                   reinterpret_cast<const unsigned long long*>(lprev)[h]);
+        if (t + nx < ntiles) dma(t + nx, buf ^ 1);
+        int wcount = 0;
+        if (active) {
+            // fragment address = lane row base + compile-time row offset + ((32 s) ^ G): the swizzle term depends on
+            // the lane only through G.  G is made opaque per 32-row step so that the fragment addresses are recomputed
+            // (one v_xor each) instead of being hoisted out of the loops into live registers (spills at KS = 16).
+            int G = (fh ^ ((frow >> FS) & FM)) << 4;
+            const unsigned char* lb = tilebuf + (size_t)buf * TILE_CHUNKS * 16 + frow * CPR * 16;
+            const uint32_t list_addr =
+                (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)(hitbase + buf * LIST_STRIDE);
+            const bool full = (long long)(t + 1) * SCAN_ROWS <= nrows;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+            for (int rq = 0; rq < SCAN_ROWS / 32; ++rq) {
+                asm volatile("" : "+v"(G));
+                const int prow = t * SCAN_ROWS + rq * 32 + 4 * fh;
+                const unsigned char* lq = lb + rq * 32 * CPR * 16;
+                if (second) {
+                    if (full) quarter(I2{}, std::true_type{}, lq, G, prow, list_addr, wcount);
+                    else      quarter(I2{}, std::false_type{}, lq, G, prow, list_addr, wcount);
+                } else {
+                    if (full) quarter(I1{}, std::true_type{}, lq, G, prow, list_addr, wcount);
+                    else      quarter(I1{}, std::false_type{}, lq, G, prow, list_addr, wcount);
+                }
+            }
+        }
+        if (lane < npend && lane < 64) {
+            const int q = reinterpret_cast<const int*>(lprev + SCAN_WHITS * 8)[lane];
+            if (pos < cap) cand[(long long)q * cap + pos] = reinterpret_cast<const unsigned long long*>(lprev)[lane];
+        }
+        wprev = wcount;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of tile t+nx landed, my hit stores done
+        __syncthreads();                 // tile t consumed by every wave, tile t+nx visible
+    }
+    // the last tile's hits
+    const unsigned char* llast = hitbase + ((it & 1) ^ 1) * LIST_STRIDE;
+    const int nlast = wprev < SCAN_WHITS ? wprev : SCAN_WHITS;
+    for (int h = lane; h < nlast; h += 64)
+        append(reinterpret_cast<const int*>(llast + SCAN_WHITS * 8)[h], reinterpret_cast<const unsigned long long*>(llast)[h]);
+}
+
+template <int KS>
+static hipError_t launch_scan(const uint16_t* X16, long long ld16, long long nrows, const uint16_t* Q16, int nq,
+                              const float* tau, unsigned long long* cand, int* cnt, hipStream_t st) {
+    auto kern = scan_filter_kernel<KS>;
+    constexpr size_t lds_bytes = 2ull * SCAN_ROWS * 2 * KS * 16 + SCAN_HIT_BYTES;
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const long long ntiles = (nrows + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int ny = (nq + SCAN_QGROUP - 1) / SCAN_QGROUP;
+    long long nx = 256 / ny;                       // one workgroup per CU
+    if (nx < 1) nx = 1;
+    if (nx > ntiles) nx = ntiles;
+    const int d = 16 * KS;
+    ProfScope prof("search_filter_stream128x512_bf16", 2.0 * (double)nrows * (double)nq * d,
+                   2.0 * ((double)nrows * d * ny + (double)nq * d), st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nx * ny)), dim3(512), lds_bytes, st, X16, ld16, nrows, Q16, nq, tau, cand, cnt,
+                       CAND_CAP, (int)nx);
+    return hipGetLastError();
+}
+
 // fp32 rows -> bf16 rows (round to nearest even, NaN kept), one wave per row; optionally the maximum row norm
 // (atomic max over the float bits: norms are >= 0 so the unsigned order is the float order; NaN/inf propagate
 // and make every certificate fail -> exact fix-up path).
@@ -299,7 +574,10 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const float* x, long lon
 // rounded up, plus 2 d 2^-24 for the two fp32 accumulations being compared.
 __device__ __forceinline__ float eps_rel(int d) { return 0.00392f + (float)d * 1.2e-7f; }
 
-// step 4 of the mixed-precision search: approx sort -> prune -> fp32 re-score -> exact sort -> certificate
+// step 4 of the mixed-precision search: select a_k -> prune -> fp32 re-score -> exact sort -> certificate.
+// The candidate keys (<= 16 per thread) stay in registers for the selection: a 3-pass radix select of the k-th
+// largest approximate score (LDS histograms), then only the survivors of the pruning rule go to LDS, are re-scored
+// and sorted (typically ~1.25 k keys instead of the whole list).
 __global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long long* cand, const int* cnt, int cap,
                                                              int k, long long nrows, const float* tau,
                                                              const float* max_norm, const float* X, long long ldx,
@@ -307,8 +585,11 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long
                                                              float* outD, long long* outI, long long pos_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [cap] then qv[d]
     float* qv = reinterpret_cast<float*>(keys + cap);
+    __shared__ int hist[2048];
+    __shared__ int scratch[514];
     __shared__ float red[8];
     __shared__ int m_sh;
+    constexpr int PER = CAND_CAP / 512;                       // keys per thread (cap == CAND_CAP)
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = cnt[q];
     const int need = (int)(nrows < k ? nrows : k);
@@ -326,9 +607,12 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if (lane == 0) red[w] = ss;
     if (tid == 0) m_sh = 0;
-    int P = 2;
-    while (P < c) P <<= 1;
-    for (int i = tid; i < P; i += 512) keys[i] = (i < c) ? cand[(long long)q * cap + i] : 0ull;
+    unsigned long long mine[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + 512 * j;
+        mine[j] = (i < c) ? cand[(long long)q * cap + i] : 0ull;
+    }
     __syncthreads();
     float qn = 0.f;
 #pragma unroll
@@ -336,32 +620,61 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long
     const float eps = eps_rel(d) * sqrtf(qn) * max_norm[0];
     if (!(eps < INFINITY)) { give_up(); return; }            // NaN / inf norms: exact path (block-uniform)
     if (need == 0) { write_result(keys, 0, k, q, outD, outI, pos_offset); return; }
-    bitonic_desc(keys, P);
-    // prune: a row with approx < a_k - 2 eps has exact < a_k - eps <= exact of each of the k best-by-approx rows
-    const float cut = key_score(keys[need - 1]) - 2.f * eps;
-    for (int i = tid; i < c; i += 512)
-        if (key_score(keys[i]) >= cut && (i + 1 == c || !(key_score(keys[i + 1]) >= cut))) m_sh = i + 1;
-    __syncthreads();
-    const int m = m_sh;                                       // >= need
-    // fp32 re-score, one wave per candidate, 4 candidates in flight per wave
-    const int d4 = d >> 2;
-    for (int i0 = w; i0 < m; i0 += 32) {
-        float a[4];
-        uint32_t pos[4];
+    // a_k = need-th largest approximate score (orderable 32-bit image), radix select 11 + 11 + 10 bits
+    uint32_t prefix = 0u, pmask = 0u;
+    int rr = need;
+    const int shifts[3] = {21, 10, 0};
+    const int nbits[3] = {11, 11, 10};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = tid; i < 2048; i += 512) hist[i] = 0;
+        __syncthreads();
+        const uint32_t bm = (1u << nbits[pass]) - 1u;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t u = (uint32_t)(mine[j] >> 32);
+            if (tid + 512 * j < c && (u & pmask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & bm], 1);
+        }
+        __syncthreads();
+        const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);      // always found: c >= need >= rr
+        prefix |= (uint32_t)bin << shifts[pass];
+        pmask |= bm << shifts[pass];
+    }
+    // prune: a row with approx < a_k - 2 eps has exact < a_k - eps <= exact of each of the k best-by-approx rows
+    const float cut = f32_from_orderable(prefix) - 2.f * eps;
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (tid + 512 * j < c && key_score(mine[j]) >= cut) keys[atomicAdd(&m_sh, 1)] = mine[j];
+    __syncthreads();
+    const int m = m_sh;                                       // need <= m <= c
+    // fp32 re-score, one wave per candidate, 16 candidates (random 1 KB rows: latency-bound) in flight per wave
+    const int d4 = d >> 2;
+    constexpr int RU = 16;
+    for (int i0 = w; i0 < m; i0 += 8 * RU) {
+        float a[RU];
+        uint32_t pos[RU];
+        const f32x4* xr[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
             const int i = i0 + 8 * u;
             a[u] = 0.f;
             pos[u] = key_pos(keys[i < m ? i : i0]);
-            const f32x4* xr = reinterpret_cast<const f32x4*>(X + (long long)pos[u] * ldx);
-            for (int cc = lane; cc < d4; cc += 64) {
-                const f32x4 x = xr[cc];
-                const f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * cc]);
-                a[u] += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
-            }
+            xr[u] = reinterpret_cast<const f32x4*>(X + (long long)pos[u] * ldx);
+        }
+        // column chunk outermost: the RU row loads of one chunk are independent and go out back to back (with the
+        // row loop outside, each row's load had to return before the next row's was issued: measured 100 ns per row)
+        for (int cc = lane; cc < d4; cc += 64) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * cc]);
+            f32x4 x[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) x[u] = xr[u][cc];
+#pragma unroll
+            for (int u = 0; u < RU; ++u)       // explicit fma chain: the same rounding sequence in every slot u
+                a[u] = __builtin_fmaf(x[u][3], y[3], __builtin_fmaf(x[u][2], y[2], __builtin_fmaf(x[u][1], y[1],
+                                      __builtin_fmaf(x[u][0], y[0], a[u]))));
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RU; ++u) {
             float v = a[u];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -435,7 +748,8 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
 // half the columns (d_alg = the un-halved dimension, for the profiling hook's FLOP count)
 template <class S>
 static hipError_t run_passes(const float* X, long long ldx, long long nrows, int d, const float* Q, long long ldq,
-                             int nq, const SearchPlan& pl, char* ws, hipStream_t st, int d_alg = 0) {
+                             int nq, const SearchPlan& pl, char* ws, hipStream_t st, int d_alg = 0,
+                             bool filter = true) {
     DenseRows lq{Q, nq, (int)ldq, d, 30, 1ll << 30};
     float* tau = reinterpret_cast<float*>(ws + pl.off_tau);
     int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
@@ -446,12 +760,13 @@ static hipError_t run_passes(const float* X, long long ldx, long long nrows, int
         EpiStoreScores es{S_, pl.n_sample, nq, pl.n_sample, lps};
         hipError_t e = launch_gemm<S, false>(lps, lq, es, d, pl.n_sample, nq, st, d_alg);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(sample_threshold_kernel, dim3(nq), dim3(256), 0, st, S_, pl.n_sample, pl.n_sample,
+        hipLaunchKernelGGL(sample_threshold_kernel, dim3(nq), dim3(THR_NT), 0, st, S_, pl.n_sample, pl.n_sample,
                            pl.rank, tau);
     } else {
         hipLaunchKernelGGL(fill_f32_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, tau, (long long)nq,
                            -INFINITY);
     }
+    if (!filter) return hipGetLastError();
     DenseRows lp{X, nrows, (int)ldx, d, 30, 1ll << 30};
     EpiFilter ef{tau, reinterpret_cast<unsigned long long*>(ws + pl.off_cand), cnt, CAND_CAP, nq, nrows};
     return launch_gemm<S, false>(lp, lq, ef, d, nrows, nq, st, d_alg);
@@ -516,8 +831,8 @@ extern "C" int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld
     char* ws = reinterpret_cast<char*>(workspace);
     int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
     int* fail = reinterpret_cast<int*>(ws + pl.off_fail);
-    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));
-    HIP_TRY(hipMemsetAsync(fail, 0, (size_t)(nq + 1) * 4, st));
+    // cnt[nq] and fail[nq + 1] are adjacent in the plan: one fill
+    HIP_TRY(hipMemsetAsync(cnt, 0, (pl.off_fail - pl.off_cnt) + (size_t)(nq + 1) * 4, st));
 
     if (nrows > 0) {
         hipError_t e;
@@ -585,7 +900,8 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     REQUIRE(nrows >= 0 && nrows < (1ll << 31) - 1024, "nrows out of range");
     REQUIRE(nq >= 0 && nq < (1ll << 24), "nq out of range");
     if (nq == 0) return AMDREC_OK;
-    REQUIRE((nrows == 0 || (ld_corpus >= dim && ld_corpus % 4 == 0 && ld_bf16 >= dim && ld_bf16 % 8 == 0)) &&
+    REQUIRE((nrows == 0 || (ld_corpus >= dim && ld_corpus % 4 == 0 && ld_bf16 >= dim && ld_bf16 % 8 == 0 &&
+                            ld_bf16 < (1 << 20))) &&
                 ld_queries >= dim && ld_queries % 4 == 0,
             "leading dimensions must be >= dim; fp32 multiples of 4, bf16 multiples of 8");
     REQUIRE((corpus && corpus_bf16) || nrows == 0, "corpus is null");
@@ -600,8 +916,8 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     char* ws = reinterpret_cast<char*>(workspace);
     int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
     int* fail = reinterpret_cast<int*>(ws + pl.off_fail);
-    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));
-    HIP_TRY(hipMemsetAsync(fail, 0, (size_t)(nq + 1) * 4, st));
+    // cnt[nq] and fail[nq + 1] are adjacent in the plan: one fill
+    HIP_TRY(hipMemsetAsync(cnt, 0, (pl.off_fail - pl.off_cnt) + (size_t)(nq + 1) * 4, st));
 
     if (nrows > 0) {
         uint16_t* q16 = reinterpret_cast<uint16_t*>(ws + pl.off_q16);
@@ -612,11 +928,22 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
         const float* Q = reinterpret_cast<const float*>(q16);
         const long long ldx = ld_bf16 / 2, ldq = dim / 2;
         const int dh = dim / 2;
+        // corpus pass: the streaming kernel for the power-of-two dims it is instantiated for, else the generic tiles
+        const bool stream = dim == 32 || dim == 64 || dim == 128 || dim == 256;
         hipError_t e;
-        if (nq > 64)       e = run_passes<Shape<2, 2, 4, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim);
-        else if (nq > 32)  e = run_passes<Shape<4, 1, 2, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim);
-        else               e = run_passes<Shape<4, 1, 2, 1, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim);
+        if (nq > 64)       e = run_passes<Shape<2, 2, 4, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !stream);
+        else if (nq > 32)  e = run_passes<Shape<4, 1, 2, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !stream);
+        else               e = run_passes<Shape<4, 1, 2, 1, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !stream);
         HIP_TRY(e);
+        if (stream) {
+            const float* tau_ = reinterpret_cast<const float*>(ws + pl.off_tau);
+            unsigned long long* cand_ = reinterpret_cast<unsigned long long*>(ws + pl.off_cand);
+            if (dim == 256)      e = launch_scan<16>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, cnt, st);
+            else if (dim == 128) e = launch_scan<8>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, cnt, st);
+            else if (dim == 64)  e = launch_scan<4>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, cnt, st);
+            else                 e = launch_scan<2>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, cnt, st);
+            HIP_TRY(e);
+        }
     }
     const size_t fin_lds = (size_t)CAND_CAP * 8 + (size_t)dim * 4;
     static bool attr_done = false;

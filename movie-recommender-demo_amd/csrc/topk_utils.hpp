@@ -10,33 +10,44 @@ namespace amdrec {
 // hist[NB] in LDS; returns bin and updates r to the rank inside that bin.  All threads call.
 template <int NB, int NT>
 __device__ inline int find_bin_desc(const int* hist, int& r, int* scratch /*[NT+2]*/) {
+    // Thread t owns bins [t*PER, (t+1)*PER).  A suffix scan over the threads' sums (wave shuffles + one LDS round
+    // over the wave totals) gives each thread the count of keys in bins above its own; exactly one thread's range
+    // holds the r-th largest key.  (A serial scan by one lane cost ~25 us per call at NT = 512.)
     constexpr int PER = NB / NT;
-    const int tid = threadIdx.x;
+    constexpr int NW = NT / 64;
+    static_assert(NB % NT == 0 && NT % 64 == 0, "bins must split evenly over whole waves");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int local = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) local += hist[tid * PER + i];
-    scratch[tid] = local;
+    int incl = local;                               // inclusive suffix sum within the wave (lanes >= mine)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_down(incl, o, 64);
+        if (lane + o < 64) incl += v;
+    }
+    if (lane == 0) scratch[wv] = incl;              // wave total
+    if (tid == 0) scratch[NT] = -1;
     __syncthreads();
-    // serial suffix over NT partial sums by one wave-lane (NT <= 512: cheap)
-    if (tid == 0) {
-        int above = 0, found = -1, rr = r;
-        for (int t = NT - 1; t >= 0; --t) {
-            if (above + scratch[t] >= rr) { found = t; break; }
-            above += scratch[t];
-        }
+    int above = incl - local;                       // keys in higher bins of this wave ...
+#pragma unroll
+    for (int x = 0; x < NW; ++x)
+        if (x > wv) above += scratch[x];            // ... and of the higher waves
+    if (above < r && r <= above + local) {          // the r-th largest lies in my bins (exactly one thread)
         int bin = -1;
-        if (found >= 0) {
-            for (int i = PER - 1; i >= 0; --i) {
-                int h = hist[found * PER + i];
-                if (above + h >= rr) { bin = found * PER + i; break; }
-                above += h;
+#pragma unroll
+        for (int i = PER - 1; i >= 0; --i) {
+            const int h = hist[tid * PER + i];
+            if (bin < 0) {
+                if (above + h >= r) bin = tid * PER + i;
+                else above += h;
             }
         }
         scratch[NT] = bin;
-        scratch[NT + 1] = rr - above;
+        scratch[NT + 1] = r - above;
     }
     __syncthreads();
-    int bin = scratch[NT];
+    const int bin = scratch[NT];
     r = scratch[NT + 1];
     __syncthreads();
     return bin;

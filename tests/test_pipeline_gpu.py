@@ -130,6 +130,24 @@ def test_microbatcher_over_the_device_pipeline():
     assert sum(mb.batches) == 24 and len(mb.batches) < 24
 
 
+def test_stage1_is_bitwise_deterministic_run_to_run():
+    """The candidate lists are filled by atomics (nondeterministic order): every value that comes out must still be
+    independent of that order, bit for bit (the fp32 re-score uses one explicit fma chain in every slot)."""
+    rec, _, (user, ad, nnum) = _setup(9000, 1.0 / 16)
+    uc, un = synth.user_batch(user, nnum, 5, seed=3)
+    uc, un = torch.from_numpy(uc).cuda(), torch.from_numpy(un).cuda()
+    ref = None
+    for _ in range(12):
+        out = rec.recommend_device(uc, un, 10, 500)
+        cur = {k: out[k].clone() for k in ("ad_ids", "scores", "candidate_ids", "candidate_scores")}
+        if ref is None:
+            ref = cur
+            continue
+        for k in ref:
+            assert torch.equal(ref[k].view(torch.int32) if ref[k].dtype == torch.float32 else ref[k],
+                               cur[k].view(torch.int32) if cur[k].dtype == torch.float32 else cur[k]), k
+
+
 def test_hipgraph_replay_equals_eager():
     rec, _, (user, ad, nnum) = _setup(9000, 1.0 / 16)
     for B in (1, 5):

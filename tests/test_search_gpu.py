@@ -62,7 +62,9 @@ def test_small_corpus_all_candidates(n, nq, k):
 
 
 @pytest.mark.parametrize("n,nq,k,d", [(50_000, 37, 500, 256), (120_001, 512, 500, 256), (30_000, 64, 2048, 128),
-                                      (20_000, 3, 10, 64), (9_000, 257, 100, 32)])
+                                      (20_000, 3, 10, 64), (9_000, 257, 100, 32),
+                                      (70_000, 1100, 50, 128),      # three 512-query groups in the streaming filter
+                                      (25_000, 40, 100, 96)])       # dim outside {32,64,128,256}: generic bf16 tiles
 def test_sampled_threshold_path(n, nq, k, d):
     xb, xq = _mk(n, d, 3), _mk(nq, d, 4)
     got, ref, ora = _both(xb, xq, k)
