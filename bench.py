@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-users", type=int, default=48)
+    ap.add_argument("--cpu-users", type=int, default=192)
     ap.add_argument("--sweep", action="store_true", help="also print the search-only B sweep (stderr)")
     ap.add_argument("--ads", type=int, default=N_ADS, help="corpus size (configs[3]: 10000000)")
     ap.add_argument("--index", choices=["flat", "ivf"], default="flat", help="configs[4]: ivf")

@@ -27,6 +27,8 @@ def short(name):
                "EpiFilter": "search_filter", "EpiStoreScores": "search_sample"}.get(e.group(1), e.group(1))
         gather = "_gather" if "EmbConcatRows" in name else ""
         return f"{epi}{gather}_{32 * wp * tp}x{32 * wq * tq}"
+    if "scan_filter_kernel" in name:
+        return "search_filter_stream128x512_bf16"
     return name.split("(")[0].replace("amdrec::", "").replace("void ", "")[:60]
 
 
