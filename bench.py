@@ -248,7 +248,7 @@ def main():
                       "hbm_frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "tflops": round(sf["flops"] / sf["launches"] / (ms * 1e-3) / 1e12, 2),
                       "note": ("filter = one pass over the bf16 corpus; B=512 queries per pass, intensity 512 FLOP/B vs "
-                               "bf16 ridge 312: MFMA/L2-feed bound, not HBM bound" if mixed else
+                               "bf16 ridge 312: compute-side bound (vector issue + bf16 MFMA), see DESIGN.md section 6" if mixed else
                                "B=512 per corpus pass is fp32-FLOP bound (intensity 255 FLOP/B vs ridge 19.7)")}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
