@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMDREC_ABI_VERSION 2
+#define AMDREC_ABI_VERSION 3
 #define AMDREC_MAX_K 2048
 
 int amdrec_abi_version(void);
@@ -147,6 +147,12 @@ typedef struct {
     const float *w_2, *b_2;               /* [d_model][ldw_ff] */
     const float *ln2_g, *ln2_b;
     int32_t ldw_dm, ldw_ff;
+    /* Optional host-split planes of w_o / w_1 / w_2 for the error-compensated bf16-MFMA GEMM ("x6", used for passes of
+     * more than 8192 rows; NULL -> fp32 MFMA).  Layout [out][ldw/32][3][32] bf16: for every 32-column group the planes
+     * h, m, l of the exact 3-way truncation split w = h + m + l (h = w with the low 16 bits cleared, m = (w - h)
+     * likewise, l = w - h - m; each plane stored as the high 16 bits of that fp32 value).  Same result contract as the
+     * fp32 path: error at the level of an fp32 fma chain. */
+    const uint16_t *w_o_x6, *w_1_x6, *w_2_x6;
 } amdrec_encoder_layer;
 
 typedef struct {
@@ -181,6 +187,9 @@ typedef struct {
      * the same two addends in the same order as the uncached path (bit-identical). */
     const float* ad_proj_cache;     /* [n_ad_rows][ld_ad_proj_cache] or NULL */
     int64_t ld_ad_proj_cache;
+    /* Optional x6 planes (see amdrec_encoder_layer) of cross_wt[i] and head_w1. */
+    const uint16_t* cross_wt_x6[AMDREC_MAX_LAYERS];
+    const uint16_t* head_w1_x6;
 } amdrec_ranker_params;
 
 int amdrec_ranker_workspace(const amdrec_ranker_params* p /*host*/, int64_t rows, size_t* bytes /*host*/);

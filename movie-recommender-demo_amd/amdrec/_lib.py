@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libamdrec.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_K = 2048
 
 

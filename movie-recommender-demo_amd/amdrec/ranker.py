@@ -81,6 +81,9 @@ class TransformerRanker(nn.Module):
         # W_ov = W_o W_v pre-multiplied on the host (exact algebra at seq_len 1; set False to run the two
         # GEMMs in the reference's order)
         self.fuse_attention = True
+        # big passes (> 8192 rows) on the error-compensated bf16-MFMA GEMM ("bf16x6": fp32 inputs split exactly into
+        # three bf16 planes, six products per MAC, fp32 accumulate - fp32-level error); "fp32" = fp32 MFMA everywhere
+        self.gemm_engine = "bf16x6"
 
     # -- packing ----------------------------------------------------------------------
     def invalidate(self):
@@ -127,10 +130,13 @@ class TransformerRanker(nn.Module):
         return c[4]
 
     def _pack(self, device):
-        key = (str(device), self.fuse_attention, tuple(p._version for p in self.parameters()))
+        if self.gemm_engine not in ("bf16x6", "fp32"):
+            raise ValueError("gemm_engine must be 'bf16x6' or 'fp32'")
+        key = (str(device), self.fuse_attention, self.gemm_engine, tuple(p._version for p in self.parameters()))
         if self._packed is None or self._packed[0] != key:
             params, keep, tasks = weights.pack_ranker(self.state_dict(), self._user_names, self._ad_names,
-                                                      self._n_num, device, fuse_attention=self.fuse_attention)
+                                                      self._n_num, device, fuse_attention=self.fuse_attention,
+                                                      x6=self.gemm_engine == "bf16x6")
             self._packed = (key, params, keep, tasks)
         return self._packed[1], self._packed[3]
 

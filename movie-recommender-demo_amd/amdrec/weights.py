@@ -25,7 +25,8 @@ class TowerParams(C.Structure):
 
 class EncoderLayer(C.Structure):
     _fields_ = [(n, _FP) for n in ("w_v", "b_v", "w_o", "b_o", "ln1_g", "ln1_b", "w_1", "b_1", "w_2", "b_2",
-                                   "ln2_g", "ln2_b")] + [("ldw_dm", C.c_int32), ("ldw_ff", C.c_int32)]
+                                   "ln2_g", "ln2_b")] + [("ldw_dm", C.c_int32), ("ldw_ff", C.c_int32)] + \
+               [(n, _FP) for n in ("w_o_x6", "w_1_x6", "w_2_x6")]
 
 
 class RankerParams(C.Structure):
@@ -41,13 +42,30 @@ class RankerParams(C.Structure):
                 ("head_w1", _FP), ("head_b1", _FP),
                 ("head_w2", _FP * MAX_TASKS), ("head_b2", _FP * MAX_TASKS),
                 ("head_w3", _FP * MAX_TASKS), ("head_b3", _FP * MAX_TASKS),
-                ("ad_proj_cache", _FP), ("ld_ad_proj_cache", C.c_int64)]
+                ("ad_proj_cache", _FP), ("ld_ad_proj_cache", C.c_int64),
+                ("cross_wt_x6", _FP * MAX_LAYERS), ("head_w1_x6", _FP)]
 
 
 def _np64(t):
     if isinstance(t, torch.Tensor):
         return t.detach().cpu().double().numpy()
     return np.asarray(t, dtype=np.float64)
+
+
+def split_planes(w32: np.ndarray) -> np.ndarray:
+    """fp32 [out][ld] (ld % 32 == 0) -> uint16 [out][ld/32][3][32]: the bf16 planes h, m, l of the exact 3-way
+    truncation split w = h + m + l consumed by the x6 GEMM (include/amdrec.h, amdrec_encoder_layer)."""
+    w = np.ascontiguousarray(w32, dtype=np.float32)
+    out_f, ld = w.shape
+    assert ld % 32 == 0
+    u = w.view(np.uint32)
+    h = (u & np.uint32(0xffff0000)).view(np.float32)
+    r1 = w - h                                              # exact
+    m = (r1.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+    r2 = r1 - m                                             # exact, <= 8 significant bits
+    planes = np.stack([(x.view(np.uint32) >> np.uint32(16)).astype(np.uint16) for x in (h, m, r2)], axis=0)
+    assert np.array_equal(h + m + r2, w)                    # the split is exact
+    return np.ascontiguousarray(planes.reshape(3, out_f, ld // 32, 32).transpose(1, 2, 0, 3)).view(np.int16)
 
 
 def _pad_k(w64, mult=32):
@@ -125,11 +143,13 @@ def pack_tower(sd: Dict, prefix: str, feature_names: List[str], n_num: int, devi
 
 
 def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int, device, ln_eps=1e-5,
-                fuse_attention: bool = True):
+                fuse_attention: bool = True, x6: bool = True):
     """state_dict-like of the reference TransformerRanker -> (RankerParams, Packed, task names).
     ``fuse_attention``: pre-multiply W_ov = W_o W_v, b_ov = W_o b_v + b_o in float64 (the seq-len-1
     attention is exactly W_o(W_v x + b_v) + b_o, transformer_ranker.py:59-88 with :358), so each
-    encoder layer's attention block is one GEMM instead of two."""
+    encoder layer's attention block is one GEMM instead of two.
+    ``x6``: also upload the bf16 split planes of the big weight matrices (W_ov / W_o, fc1, fc2, cross, stacked head
+    layer 1) so that passes of more than 8192 rows run on the error-compensated bf16-MFMA GEMM."""
     pk = Packed(device)
     tables = [sd[f"user_embeddings.{n}.weight"] for n in user_names] + \
              [sd[f"ad_embeddings.{n}.weight"] for n in ad_names]
@@ -171,9 +191,13 @@ def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int
             w, ld = _pad_k(mat)
             setattr(L, dst, pk.ptr(w))
             L.ldw_dm = ld
+            if x6 and dst in ("w_o", "w_1"):
+                setattr(L, dst + "_x6", pk.ptr(split_planes(w)))
         L.b_o = pk.ptr(bo.astype(np.float32))
         w, L.ldw_ff = _pad_k(_np64(sd[f"{pre}.feed_forward.fc2.weight"]))
         L.w_2 = pk.ptr(w)
+        if x6:
+            L.w_2_x6 = pk.ptr(split_planes(w))
         p.d_ff = int(sd[f"{pre}.feed_forward.fc1.weight"].shape[0])
         for dst, src in (("b_1", "feed_forward.fc1.bias"), ("b_2", "feed_forward.fc2.bias"),
                          ("ln1_g", "norm1.weight"), ("ln1_b", "norm1.bias"),
@@ -187,6 +211,8 @@ def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int
     while f"feature_interaction.cross_weights.{c}" in sd:
         w, p.ldw_cross = _pad_k(_np64(sd[f"feature_interaction.cross_weights.{c}"]).T)   # xl @ W == xl (W^T)^T
         p.cross_wt[c] = pk.ptr(w)
+        if x6:
+            p.cross_wt_x6[c] = pk.ptr(split_planes(w))
         p.cross_b[c] = pk.ptr(_np64(sd[f"feature_interaction.cross_biases.{c}"]).astype(np.float32))
         c += 1
     p.n_cross = c
@@ -198,6 +224,8 @@ def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int
     p.head_h2 = int(sd[f"prediction_heads.{tasks[0]}.3.weight"].shape[0])
     w, p.ldw_head1 = _pad_k(w1)
     p.head_w1, p.head_b1 = pk.ptr(w), pk.ptr(b1.astype(np.float32))
+    if x6:
+        p.head_w1_x6 = pk.ptr(split_planes(w))
     for i, t in enumerate(tasks):
         w, p.ldw_head2 = _pad_k(_np64(sd[f"prediction_heads.{t}.3.weight"]))
         p.head_w2[i] = pk.ptr(w)

@@ -320,4 +320,206 @@ inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, 
     return hipGetLastError();
 }
 
+// ======================================================================================================
+// Error-compensated fp32 GEMM on the bf16 MFMA ("x6"): the same C[p][q] = sum_k P[p][k] * Q[q][k] with fp32 inputs and
+// fp32-level accuracy at up to 16/6 = 2.67x the fp32 MFMA rate.
+//  * every fp32 value is split EXACTLY into three bf16 planes h + m + l (truncation split: 8 + 8 + 8 significand bits;
+//    x - h and (x - h) - m are exact in fp32);
+//  * the products hh, hm, mh, mm, hl, lh are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (bf16 x bf16 is exact in
+//    fp32); the dropped ml, lm, ll terms are <= 2^-23 of the product.  Measured against float64 (tools/x6_probe.hip,
+//    K = 256 / 1024): max error 1.17e-6 / 4.3e-6 vs 1.15e-6 / 3.4e-6 for an fp32 fma chain - the same error level as the
+//    fp32 MFMA path, which is why it may replace it inside the stated tolerances (tests/cases.py);
+//  * P (the weights) is pre-split once on the host: [rows][K/32][3 planes][32] bf16, so a staged row segment is 192
+//    contiguous bytes; Q (the activations) stays fp32 in HBM and is split while it is staged (5.5 VALU per element,
+//    ~11 % of the MFMA time of a K-step);
+//  * tile 256 (P) x 256 (Q), 8 waves (2 x 4), wave tile 128 x 64 = the accumulator layout of ShapeWide, so every
+//    epilogue is shared; 48 KB of LDS per operand and K-step (3 planes x 16 KB): P single-buffered with register
+//    prefetch, Q double-buffered so that its split + LDS stores run before the barrier, under the other waves' MFMAs;
+//    144 KB, one workgroup per CU; LDS image per plane [row][4 chunks of 8 bf16], chunk index XOR (row>>2)&3 (conflict-free b128).
+struct PlaneRows {
+    const uint16_t* base;   // [rows][ksteps][3][32] bf16
+    int rows;
+    int ksteps;
+};
+struct ShapeX6 {
+    static constexpr int WP = 2, WQ = 4, TP = 4, TQ = 2;
+    static constexpr int NT = 512, BP = 256, BQ = 256;
+    static constexpr int PLANE_BYTES = 256 * 4 * 16;
+    static constexpr size_t LDS_BYTES = 9 * PLANE_BYTES;     // P planes + two Q buffers
+};
+
+__device__ __forceinline__ int x6_lds_off(int plane, int row, int chunk) {
+    return ((plane * 256 + row) * 4 + (chunk ^ ((row >> 2) & 3))) * 16;
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// exact 3-way truncation split of 8 floats -> three packed bf16x8
+__device__ __forceinline__ void x6_split8(const f32x4& a, const f32x4& b, u32x4& h, u32x4& m, u32x4& l) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    uint32_t hb[8], mb[8], lb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t u = __float_as_uint(x[i]);
+        const float r1 = x[i] - __uint_as_float(u & 0xffff0000u);          // exact
+        const uint32_t ru = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(ru & 0xffff0000u);           // exact, <= 8 significant bits
+        hb[i] = u; mb[i] = ru; lb[i] = __float_as_uint(r2);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                          // high halves of two floats -> one dword
+        h[i] = __builtin_amdgcn_perm(hb[2 * i + 1], hb[2 * i], 0x07060302u);
+        m[i] = __builtin_amdgcn_perm(mb[2 * i + 1], mb[2 * i], 0x07060302u);
+        l[i] = __builtin_amdgcn_perm(lb[2 * i + 1], lb[2 * i], 0x07060302u);
+    }
+}
+
+template <class LoadQ, class Epi>
+__global__ __launch_bounds__(512, 1) void gemm_x6_kernel(PlaneRows lp, LoadQ lq, Epi epi, int ksteps, TileMap tm) {
+    using S = ShapeX6;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* sP = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* sQ = sP + 3 * S::PLANE_BYTES;
+    int small, big;
+    if (!tm.get(blockIdx.x, small, big)) return;
+    const long long prow0 = (long long)small * S::BP, qrow0 = (long long)big * S::BQ;   // P (weights) is the small operand
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w / S::WQ, wq = w % S::WQ;
+
+    // staging maps.  P: 3072 16-byte chunks per K-step, L = u * 512 + tid -> row L / 12, chunk-in-row L % 12 (plane =
+    // /4, chunk = %4): 192 contiguous bytes per row.  Q: 1024 8-float chunks, L = u * 512 + tid -> row L / 4, chunk L % 4.
+    uint32_t pg[6], pl[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int L = u * S::NT + tid, row = L / 12, within = L % 12;
+        long long r = prow0 + row;
+        r = r < lp.rows ? r : lp.rows - 1;                                  // clamped (epilogues guard on the feature index)
+        pg[u] = (uint32_t)((r * lp.ksteps) * 192 + within * 16);
+        pl[u] = (uint32_t)x6_lds_off(within / 4, row, within % 4);
+    }
+    typename LoadQ::RowState qs[2];
+    const int qc = tid & 3;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) qs[u] = lq.row_state(qrow0 + u * 128 + (tid >> 2));
+    u32x4 rp[6];
+    f32x4 rq[4];
+    auto load_stage = [&](int kt) {
+        const unsigned char* gb = reinterpret_cast<const unsigned char*>(lp.base) + (size_t)kt * 192;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) rp[u] = *reinterpret_cast<const u32x4*>(gb + pg[u]);
+        const int k = kt * BK + qc * 8;
+        const bool v0 = lq.k_valid(k), v1 = lq.k_valid(k + 4);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            rq[2 * u] = v0 ? lq.load(qs[u], k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rq[2 * u + 1] = v1 ? lq.load(qs[u], k + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // Q is double-buffered: its split + stores go to the other buffer BEFORE the barrier that ends a K-step (under the
+    // other waves' MFMAs); only the plain copies of the P planes sit between the two barriers
+    auto store_q = [&](int buf) {
+        unsigned char* dst = sQ + buf * 3 * S::PLANE_BYTES;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = u * 128 + (tid >> 2);
+            u32x4 h, m, l;
+            x6_split8(rq[2 * u], rq[2 * u + 1], h, m, l);
+            *reinterpret_cast<u32x4*>(dst + x6_lds_off(0, row, qc)) = h;
+            *reinterpret_cast<u32x4*>(dst + x6_lds_off(1, row, qc)) = m;
+            *reinterpret_cast<u32x4*>(dst + x6_lds_off(2, row, qc)) = l;
+        }
+    };
+    auto store_p = [&]() {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) *reinterpret_cast<u32x4*>(sP + pl[u]) = rp[u];
+    };
+
+    Acc<S::TP, S::TQ, S::WP, S::WQ> acc;
+    acc.p0 = (int)prow0 + wp * S::TP * 32;
+    acc.q0 = (int)qrow0 + wq * S::TQ * 32;
+    acc.wp = wp;
+    acc.wq = wq;
+#pragma unroll
+    for (int i = 0; i < S::TP; ++i)
+#pragma unroll
+        for (int j = 0; j < S::TQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
+
+    load_stage(0);
+    store_q(0);
+    store_p();
+    __syncthreads();
+    const int frow = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < ksteps; ++kt) {
+        const bool more = kt + 1 < ksteps;
+        if (more) load_stage(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = 2 * s + fh;
+            bf16x8 b[S::TQ][3];
+#pragma unroll
+            for (int j = 0; j < S::TQ; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[j][p] = *reinterpret_cast<const bf16x8*>(sQ + (kt & 1) * 3 * S::PLANE_BYTES +
+                                                               x6_lds_off(p, wq * 64 + j * 32 + frow, chunk));
+            // P plane h with Q planes l, m, h; P plane m with Q planes m, h; P plane l with Q plane h
+#pragma unroll
+            for (int pa = 0; pa < 3; ++pa) {
+                bf16x8 a[S::TP];
+#pragma unroll
+                for (int i = 0; i < S::TP; ++i)
+                    a[i] = *reinterpret_cast<const bf16x8*>(sP + x6_lds_off(pa, wp * 128 + i * 32 + frow, chunk));
+#pragma unroll
+                for (int pb = 2 - pa; pb >= 0; --pb)
+#pragma unroll
+                    for (int i = 0; i < S::TP; ++i)
+#pragma unroll
+                        for (int j = 0; j < S::TQ; ++j)
+                            acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j][pb], acc.v[i][j], 0, 0, 0);
+            }
+        }
+        if (more) store_q((kt + 1) & 1);
+        __syncthreads();               // every wave has read the P planes of this K-step (and the Q buffer of the last)
+        if (more) {
+            store_p();
+            __syncthreads();
+        }
+    }
+    epi(acc, smem);
+}
+
+// P = pre-split weights (the small operand), Q = fp32 rows.  K = padded K of the weights (multiple of 32).
+template <class LoadQ, class Epi>
+inline hipError_t launch_gemm_x6(const uint16_t* planes, int p_rows, const LoadQ& lq, const Epi& epi, int K,
+                                 long long q_rows, hipStream_t stream, int k_alg = 0) {
+    using S = ShapeX6;
+    auto kern = gemm_x6_kernel<LoadQ, Epi>;
+    constexpr size_t lds_bytes = S::LDS_BYTES > Epi::lds_bytes(S::NT / 64) ? S::LDS_BYTES : Epi::lds_bytes(S::NT / 64);
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    TileMap tm;
+    tm.tiles_small = (p_rows + S::BP - 1) / S::BP;
+    tm.tiles_big = (int)((q_rows + S::BQ - 1) / S::BQ);
+    if (tm.tiles_small <= 0 || tm.tiles_big <= 0) return hipSuccess;
+    const int ksteps = K / BK;
+    PlaneRows lp{planes, p_rows, ksteps};
+    char tag[64];
+    if (g_prof_on) snprintf(tag, sizeof(tag), "%s_%dx%d_x6", Epi::name, S::BP, S::BQ);
+    const double ka = k_alg > 0 ? k_alg : K;
+    ProfScope prof(tag, 2.0 * (double)p_rows * (double)q_rows * ka,
+                   4.0 * ((double)p_rows * ka + (double)q_rows * ka) +
+                       4.0 * Epi::out_bytes_per_elem * (double)p_rows * (double)q_rows,
+                   stream);
+    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(S::NT), lds_bytes, stream, lp, lq, epi, ksteps, tm);
+    return hipGetLastError();
+}
+
 }  // namespace amdrec

@@ -9,6 +9,7 @@
 //   ranker (transformer_ranker.py:332-380): gather+concat -> Linear(+pos[0]) ->
 //          3x { x = LN(x + W_o(W_v x)) ; x = LN(x + W_2 relu(W_1 x)) } -> 3x cross -> 3 heads
 //          (seq_len == 1, :358, makes the attention exactly W_o(W_v x + b_v) + b_o: SURVEY fact 1)
+#include <type_traits>
 #include "gemm_core.hpp"
 #include "../../include/amdrec.h"
 
@@ -451,18 +452,35 @@ static hipError_t linear_shapes(const float* W, int ldw, int nout, const LoadQ& 
     if (nout % SW::BP == 0) return launch_gemm<SW, true>(lp, lq, EpiT<true>{ea...}, ldw, nout, rows, st, k_alg);
     return launch_gemm<SW, true>(lp, lq, EpiT<false>{ea...}, ldw, nout, rows, st, k_alg);
 }
+// The error-compensated bf16 path (gemm_core.hpp "x6") for the big passes: needs the host-split weight planes, a dense
+// fp32 row operand and at least one full 256-feature tile.
+template <template <bool> class EpiT, class LoadQ, class... EpiArgs>
+static bool try_x6(hipError_t& e, const uint16_t* Wx6, int ldw, int nout, const LoadQ& lq, long long rows, hipStream_t st,
+                   int k_alg, EpiArgs... ea) {
+    if constexpr (std::is_same<LoadQ, DenseRows>::value) {
+        if (Wx6 == nullptr || rows <= SMALL_ROWS || nout < 256) return false;
+        if (nout % 256 == 0) e = launch_gemm_x6(Wx6, nout, lq, EpiT<true>{ea...}, ldw, rows, st, k_alg);
+        else e = launch_gemm_x6(Wx6, nout, lq, EpiT<false>{ea...}, ldw, rows, st, k_alg);
+        return true;
+    }
+    return false;
+}
 // narrow outputs (<= 64 features) may use the 64-feature shapes
 template <template <bool> class EpiT, class LoadQ, class... EpiArgs>
-static hipError_t linear(const float* W, int ldw, int nout, const LoadQ& lq, long long rows, hipStream_t st,
-                         int k_alg, EpiArgs... ea) {
+static hipError_t linear(const float* W, const uint16_t* Wx6, int ldw, int nout, const LoadQ& lq, long long rows,
+                         hipStream_t st, int k_alg, EpiArgs... ea) {
+    hipError_t e;
+    if (try_x6<EpiT>(e, Wx6, ldw, nout, lq, rows, st, k_alg, ea...)) return e;
     if (rows <= SMALL_ROWS)
         return linear_shapes<ShapeSmall, ShapeSmallNarrow, true, EpiT>(W, ldw, nout, lq, rows, st, k_alg, ea...);
     return linear_shapes<ShapeWide, ShapeNarrow, true, EpiT>(W, ldw, nout, lq, rows, st, k_alg, ea...);
 }
 // epilogues that need a whole 256-feature row in one workgroup (LayerNorm, L2 norm)
 template <template <bool> class EpiT, class LoadQ, class... EpiArgs>
-static hipError_t linear_wide(const float* W, int ldw, int nout, const LoadQ& lq, long long rows, hipStream_t st,
-                              int k_alg, EpiArgs... ea) {
+static hipError_t linear_wide(const float* W, const uint16_t* Wx6, int ldw, int nout, const LoadQ& lq, long long rows,
+                              hipStream_t st, int k_alg, EpiArgs... ea) {
+    hipError_t e;
+    if (try_x6<EpiT>(e, Wx6, ldw, nout, lq, rows, st, k_alg, ea...)) return e;
     if (rows <= SMALL_ROWS)
         return linear_shapes<ShapeSmall, ShapeSmallNarrow, false, EpiT>(W, ldw, nout, lq, rows, st, k_alg, ea...);
     return linear_shapes<ShapeWide, ShapeNarrow, false, EpiT>(W, ldw, nout, lq, rows, st, k_alg, ea...);
@@ -556,15 +574,15 @@ extern "C" int amdrec_tower_forward(const amdrec_tower_params* p, const int64_t*
             hipError_t e;
             if (last) {
                 float* dst = out + r0 * ld_out;
-                e = (l == 0) ? linear_wide<EpiL2NormT>(p->w[l], p->ldw[l], nout, g, m, st, p->dims[l], p->b[l], dst,
+                e = (l == 0) ? linear_wide<EpiL2NormT>(p->w[l], nullptr, p->ldw[l], nout, g, m, st, p->dims[l], p->b[l], dst,
                                                        (long long)ld_out, m, nout, 1e-12f)
-                             : linear_wide<EpiL2NormT>(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), m, st,
+                             : linear_wide<EpiL2NormT>(p->w[l], nullptr, p->ldw[l], nout, dense(cur, m, curw, curw), m, st,
                                                        p->dims[l], p->b[l], dst, (long long)ld_out, m, nout, 1e-12f);
             } else {
                 float* dst = bufs[l & 1];
-                e = (l == 0) ? linear<EpiLinearT>(p->w[l], p->ldw[l], nout, g, m, st, p->dims[l], p->b[l], dst,
+                e = (l == 0) ? linear<EpiLinearT>(p->w[l], nullptr, p->ldw[l], nout, g, m, st, p->dims[l], p->b[l], dst,
                                                   (long long)nout, m, nout, 1)
-                             : linear<EpiLinearT>(p->w[l], p->ldw[l], nout, dense(cur, m, curw, curw), m, st,
+                             : linear<EpiLinearT>(p->w[l], nullptr, p->ldw[l], nout, dense(cur, m, curw, curw), m, st,
                                                   p->dims[l], p->b[l], dst, (long long)nout, m, nout, 1);
                 cur = dst;
                 curw = nout;
@@ -664,7 +682,7 @@ extern "C" int amdrec_ranker_project_ads(const amdrec_ranker_params* p, const in
     ga.row_base = 0; ga.rows = n_ads; ga.rows1 = n_ads; ga.F = F - F0; ga.F0 = 0; ga.E = p->emb_dim;
     ga.eshift = ilog2(p->emb_dim); ga.n_num = 0; ga.cat0_rowdiv = 1;
     // the same GEMM (shape, K order) as the uncached candidate half, with an all-zero "user row"
-    HIP_TRY(linear_wide<EpiRowBiasT>(p->w_proj_ad, p->ldw_proj_ad, dm, ga, n_ads, st, (F - F0) * p->emb_dim,
+    HIP_TRY(linear_wide<EpiRowBiasT>(p->w_proj_ad, nullptr, p->ldw_proj_ad, dm, ga, n_ads, st, (F - F0) * p->emb_dim,
                                      (const float*)zero, out, (long long)ld_out, n_ads, 0ll, 0x7fffffff, dm));
     return AMDREC_OK;
 }
@@ -719,7 +737,7 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         gu.cat0 = (const long long*)user_cat; gu.cat1 = nullptr; gu.rowmap1 = nullptr; gu.num = numerical;
         gu.row_base = 0; gu.rows1 = 1; gu.rows = n_users; gu.F = F0; gu.F0 = F0; gu.E = p->emb_dim;
         gu.eshift = ilog2(p->emb_dim); gu.n_num = p->n_num; gu.cat0_rowdiv = 1;
-        HIP_TRY(linear_wide<EpiLinearT>(p->w_proj_user, p->ldw_proj_user, dm, gu, n_users, st,
+        HIP_TRY(linear_wide<EpiLinearT>(p->w_proj_user, nullptr, p->ldw_proj_user, dm, gu, n_users, st,
                                         F0 * p->emb_dim + p->n_num, p->b_proj, U, (long long)dm, n_users, dm, 0));
     }
     for (long long r0 = 0; r0 < rows; r0 += w.chunk) {
@@ -743,10 +761,10 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
             EmbConcatRows ga = g;
             ga.off = p->table_off + F0; ga.card = p->cards + F0;
             ga.cat0 = nullptr; ga.num = nullptr; ga.n_num = 0; ga.F = F - F0; ga.F0 = 0; ga.cat0_rowdiv = 1;
-            HIP_TRY(linear_wide<EpiRowBiasT>(p->w_proj_ad, p->ldw_proj_ad, dm, ga, m, st, (F - F0) * p->emb_dim,
+            HIP_TRY(linear_wide<EpiRowBiasT>(p->w_proj_ad, nullptr, p->ldw_proj_ad, dm, ga, m, st, (F - F0) * p->emb_dim,
                                              (const float*)U, X, (long long)dm, m, r0, (int)user_rowdiv, dm));
         } else {
-            HIP_TRY(linear_wide<EpiLinearT>(p->w_proj, p->ldw_proj, dm, g, m, st, F * p->emb_dim + p->n_num,
+            HIP_TRY(linear_wide<EpiLinearT>(p->w_proj, nullptr, p->ldw_proj, dm, g, m, st, F * p->emb_dim + p->n_num,
                                             p->b_proj, X, (long long)dm, m, dm, 0));
         }
         // ---- encoder layers ----
@@ -754,23 +772,23 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
             const amdrec_encoder_layer& L = p->layers[l];
             if (L.w_v != nullptr) {
                 // T = W_v x + b_v ; X = LN1(X + W_o T + b_o)
-                HIP_TRY(linear_wide<EpiLinearT>(L.w_v, L.ldw_dm, dm, dense(X, m, dm, dm), m, st, dm, L.b_v, T,
+                HIP_TRY(linear_wide<EpiLinearT>(L.w_v, nullptr, L.ldw_dm, dm, dense(X, m, dm, dm), m, st, dm, L.b_v, T,
                                                 (long long)dm, m, dm, 0));
-                HIP_TRY(linear_wide<EpiResidualLNT>(L.w_o, L.ldw_dm, dm, dense(T, m, dm, dm), m, st, dm, L.b_o,
+                HIP_TRY(linear_wide<EpiResidualLNT>(L.w_o, L.w_o_x6, L.ldw_dm, dm, dense(T, m, dm, dm), m, st, dm, L.b_o,
                                                     (const float*)X, L.ln1_g, L.ln1_b, X, (long long)dm, m, dm,
                                                     p->ln_eps));
             } else {
                 // host pre-multiplied W_ov = W_o W_v: LN1(X + W_ov X + b_ov), written to the spare buffer
-                HIP_TRY(linear_wide<EpiResidualLNT>(L.w_o, L.ldw_dm, dm, dense(X, m, dm, dm), m, st, dm, L.b_o,
+                HIP_TRY(linear_wide<EpiResidualLNT>(L.w_o, L.w_o_x6, L.ldw_dm, dm, dense(X, m, dm, dm), m, st, dm, L.b_o,
                                                     (const float*)X, L.ln1_g, L.ln1_b, T, (long long)dm, m, dm,
                                                     p->ln_eps));
                 float* tmp = X; X = T; T = tmp;
             }
             // H = relu(W_1 X + b_1)
-            HIP_TRY(linear<EpiLinearT>(L.w_1, L.ldw_dm, p->d_ff, dense(X, m, dm, dm), m, st, dm, L.b_1, H,
+            HIP_TRY(linear<EpiLinearT>(L.w_1, L.w_1_x6, L.ldw_dm, p->d_ff, dense(X, m, dm, dm), m, st, dm, L.b_1, H,
                                        (long long)p->d_ff, m, p->d_ff, 1));
             // X = LN2(X + W_2 H + b_2)
-            HIP_TRY(linear_wide<EpiResidualLNT>(L.w_2, L.ldw_ff, dm, dense(H, m, p->d_ff, p->d_ff), m, st, p->d_ff,
+            HIP_TRY(linear_wide<EpiResidualLNT>(L.w_2, L.w_2_x6, L.ldw_ff, dm, dense(H, m, p->d_ff, p->d_ff), m, st, p->d_ff,
                                                 L.b_2, (const float*)X, L.ln2_g, L.ln2_b, X, (long long)dm, m, dm,
                                                 p->ln_eps));
         }
@@ -778,7 +796,7 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         const float* xl = X;
         for (int c = 0; c < p->n_cross; ++c) {
             float* dst = (c & 1) ? X0 : T;
-            HIP_TRY(linear_wide<EpiCrossT>(p->cross_wt[c], p->ldw_cross, dm, dense(xl, m, dm, dm), m, st, dm,
+            HIP_TRY(linear_wide<EpiCrossT>(p->cross_wt[c], p->cross_wt_x6[c], p->ldw_cross, dm, dense(xl, m, dm, dm), m, st, dm,
                                            p->cross_b[c], (const float*)X, xl, dst, (long long)dm, m, dm));
             xl = dst;
         }
@@ -786,10 +804,10 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         const int h1 = p->head_h1, h2 = p->head_h2, nt = p->n_tasks;
         float* H1 = H;                                   // [m][nt*h1]
         float* H2 = H + (size_t)m * nt * h1;             // [m][nt*h2]
-        HIP_TRY(linear<EpiLinearT>(p->head_w1, p->ldw_head1, nt * h1, dense(xl, m, dm, dm), m, st, dm, p->head_b1, H1,
+        HIP_TRY(linear<EpiLinearT>(p->head_w1, p->head_w1_x6, p->ldw_head1, nt * h1, dense(xl, m, dm, dm), m, st, dm, p->head_b1, H1,
                                    (long long)nt * h1, m, nt * h1, 1));
         for (int t = 0; t < nt; ++t) {
-            HIP_TRY(linear<EpiLinearT>(p->head_w2[t], p->ldw_head2, h2, dense(H1 + t * h1, m, (long long)nt * h1, h1), m,
+            HIP_TRY(linear<EpiLinearT>(p->head_w2[t], nullptr, p->ldw_head2, h2, dense(H1 + t * h1, m, (long long)nt * h1, h1), m,
                                        st, h1, p->head_b2[t], H2 + t * h2, (long long)nt * h2, m, h2, 1));
             hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, st,
                                H2 + t * h2, (long long)nt * h2, h2, p->head_w3[t], p->head_b3[t],

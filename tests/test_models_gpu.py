@@ -128,6 +128,30 @@ def test_ranker_score_candidates_broadcast_and_gather():
         assert ok, (t, err)
 
 
+@pytest.mark.parametrize("cross", ["scaled", "randn"])
+def test_ranker_large_pass_on_the_split_bf16_gemm_matches_oracle_and_fp32_engine(cross):
+    """Passes of more than 8192 rows run the error-compensated bf16-MFMA GEMM (gemm_engine 'bf16x6'): same tolerance
+    against the oracle as the fp32-MFMA engine, and the two engines agree to fp32 rounding level."""
+    m, sd, (user, ad, nnum), _ = _ranker("demo", cross)
+    U, k, N = 24, 500, 30_000                                            # 12000 rows
+    uc, un = synth.user_batch(user, nnum, U, seed=29)
+    table = synth.ad_features(ad, N, seed=30)
+    cand = np.random.default_rng(31).integers(0, N, (U, k))
+    assert m.gemm_engine == "bf16x6"
+    x6 = m.score_candidates(_cu(uc), _cu(un), _cu(cand), _cu(table), check_indices=True)
+    m.gemm_engine = "fp32"
+    f32 = m.score_candidates(_cu(uc), _cu(un), _cu(cand), _cu(table))
+    ref = oracle.ranker.forward(sd, np.repeat(uc, k, axis=0), table[cand.reshape(-1)], np.repeat(un, k, axis=0))
+    scale = cases.logit_scale(ref)
+    for t in ref:
+        for name, got in (("x6", x6), ("fp32", f32)):
+            ok, err = cases.logit_close(got[t].cpu().numpy(), ref[t], scale=scale)
+            assert ok, (name, t, err)
+        d = (x6[t] - f32[t]).abs().max().item()
+        assert d <= 2 * cases.LOGIT_SCALE_RTOL * scale + 1e-6, (t, d, scale)          # two fp32-level evaluations
+        assert not torch.equal(x6[t], f32[t])                            # it really is a different code path
+
+
 def test_ranker_ad_projection_cache_is_bit_identical_and_invalidates():
     """cache_ad_projection: the cached (row-gather) form of the candidate half of the projection returns exactly the
     logits of the GEMM form; a weight update or another table drops it (the GEMM form runs again)."""
