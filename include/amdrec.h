@@ -148,7 +148,7 @@ typedef struct {
     const float *ln2_g, *ln2_b;
     int32_t ldw_dm, ldw_ff;
     /* Optional host-split planes of w_o / w_1 / w_2 for the error-compensated bf16-MFMA GEMM ("x6", used for passes of
-     * more than 8192 rows; NULL -> fp32 MFMA).  Layout [out][ldw/32][3][32] bf16: for every 32-column group the planes
+     * more than 8192 rows; NULL -> fp32 MFMA).  Layout [out][ldw/16][3][16] bf16: for every 16-column group the planes
      * h, m, l of the exact 3-way truncation split w = h + m + l (h = w with the low 16 bits cleared, m = (w - h)
      * likewise, l = w - h - m; each plane stored as the high 16 bits of that fp32 value).  Same result contract as the
      * fp32 path: error at the level of an fp32 fma chain. */

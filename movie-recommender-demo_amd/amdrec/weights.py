@@ -53,7 +53,7 @@ def _np64(t):
 
 
 def split_planes(w32: np.ndarray) -> np.ndarray:
-    """fp32 [out][ld] (ld % 32 == 0) -> uint16 [out][ld/32][3][32]: the bf16 planes h, m, l of the exact 3-way
+    """fp32 [out][ld] (ld % 32 == 0) -> int16 view of [out][ld/16][3][16]: the bf16 planes h, m, l of the exact 3-way
     truncation split w = h + m + l consumed by the x6 GEMM (include/amdrec.h, amdrec_encoder_layer)."""
     w = np.ascontiguousarray(w32, dtype=np.float32)
     out_f, ld = w.shape
@@ -65,7 +65,7 @@ def split_planes(w32: np.ndarray) -> np.ndarray:
     r2 = r1 - m                                             # exact, <= 8 significant bits
     planes = np.stack([(x.view(np.uint32) >> np.uint32(16)).astype(np.uint16) for x in (h, m, r2)], axis=0)
     assert np.array_equal(h + m + r2, w)                    # the split is exact
-    return np.ascontiguousarray(planes.reshape(3, out_f, ld // 32, 32).transpose(1, 2, 0, 3)).view(np.int16)
+    return np.ascontiguousarray(planes.reshape(3, out_f, ld // 16, 16).transpose(1, 2, 0, 3)).view(np.int16)
 
 
 def _pad_k(w64, mult=32):

@@ -329,28 +329,26 @@ inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, 
 //    fp32); the dropped ml, lm, ll terms are <= 2^-23 of the product.  Measured against float64 (tools/x6_probe.hip,
 //    K = 256 / 1024): max error 1.17e-6 / 4.3e-6 vs 1.15e-6 / 3.4e-6 for an fp32 fma chain - the same error level as the
 //    fp32 MFMA path, which is why it may replace it inside the stated tolerances (tests/cases.py);
-//  * P (the weights) is pre-split once on the host: [rows][K/32][3 planes][32] bf16, so a staged row segment is 192
-//    contiguous bytes; Q (the activations) stays fp32 in HBM and is split while it is staged (5.5 VALU per element,
-//    ~11 % of the MFMA time of a K-step);
-//  * tile 256 (P) x 256 (Q), 8 waves (2 x 4), wave tile 128 x 64 = the accumulator layout of ShapeWide, so every
-//    epilogue is shared; 48 KB of LDS per operand and K-step (3 planes x 16 KB): P single-buffered with register
-//    prefetch, Q double-buffered so that its split + LDS stores run before the barrier, under the other waves' MFMAs;
-//    144 KB, one workgroup per CU; LDS image per plane [row][4 chunks of 8 bf16], chunk index XOR (row>>2)&3 (conflict-free b128).
+//  * P (the weights) is pre-split once on the host: [rows][K/16][3 planes][16] bf16, so the record of a row for one
+//    K-step is 96 contiguous bytes; Q (the activations) stays fp32 in HBM and is split while it is staged (5.5 VALU per
+//    element);
+//  * same workgroup geometry as ShapeWide (256 x 128 tile, 4 waves, wave tile 128 x 64, two workgroups per CU), so every
+//    epilogue is shared; a K-step is ONE v_mfma k16 step (48 MFMAs per wave) and everything is double-buffered in LDS
+//    (72 KB per workgroup): the P planes arrive by LDS-DMA (no registers), the Q rows through 8 registers + split, both
+//    for step k+1 while step k computes - ONE barrier per K-step, nothing between barriers;
+//  * LDS image per operand [row][plane][2 chunks of 8 bf16] = 96 B per row (what the DMA writes linearly), chunk index
+//    XOR (row>>3)&1 (source-side for P): a fragment read is base + compile-time offset, conflict-free ds_read_b128.
 struct PlaneRows {
-    const uint16_t* base;   // [rows][ksteps][3][32] bf16
+    const uint16_t* base;   // [rows][ksteps][3][16] bf16
     int rows;
-    int ksteps;
+    int ksteps;             // K / 16
 };
 struct ShapeX6 {
-    static constexpr int WP = 2, WQ = 4, TP = 4, TQ = 2;
-    static constexpr int NT = 512, BP = 256, BQ = 256;
-    static constexpr int PLANE_BYTES = 256 * 4 * 16;
-    static constexpr size_t LDS_BYTES = 9 * PLANE_BYTES;     // P planes + two Q buffers
+    static constexpr int WP = 2, WQ = 2, TP = 4, TQ = 2;
+    static constexpr int NT = 256, BP = 256, BQ = 128, BK16 = 16;
+    static constexpr int P_BYTES = BP * 96, Q_BYTES = BQ * 96;           // one K-step of one operand
+    static constexpr size_t LDS_BYTES = 2 * (P_BYTES + Q_BYTES);
 };
-
-__device__ __forceinline__ int x6_lds_off(int plane, int row, int chunk) {
-    return ((plane * 256 + row) * 4 + (chunk ^ ((row >> 2) & 3))) * 16;
-}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // exact 3-way truncation split of 8 floats -> three packed bf16x8
@@ -374,11 +372,11 @@ __device__ __forceinline__ void x6_split8(const f32x4& a, const f32x4& b, u32x4&
 }
 
 template <class LoadQ, class Epi>
-__global__ __launch_bounds__(512, 1) void gemm_x6_kernel(PlaneRows lp, LoadQ lq, Epi epi, int ksteps, TileMap tm) {
+__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(PlaneRows lp, LoadQ lq, Epi epi, int ksteps, TileMap tm) {
     using S = ShapeX6;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned char* sP = reinterpret_cast<unsigned char*>(smem);
-    unsigned char* sQ = sP + 3 * S::PLANE_BYTES;
+    unsigned char* sP = reinterpret_cast<unsigned char*>(smem);           // [2][P_BYTES]
+    unsigned char* sQ = sP + 2 * S::P_BYTES;                               // [2][Q_BYTES]
     int small, big;
     if (!tm.get(blockIdx.x, small, big)) return;
     const long long prow0 = (long long)small * S::BP, qrow0 = (long long)big * S::BQ;   // P (weights) is the small operand
@@ -386,52 +384,41 @@ __global__ __launch_bounds__(512, 1) void gemm_x6_kernel(PlaneRows lp, LoadQ lq,
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / S::WQ, wq = w % S::WQ;
 
-    // staging maps.  P: 3072 16-byte chunks per K-step, L = u * 512 + tid -> row L / 12, chunk-in-row L % 12 (plane =
-    // /4, chunk = %4): 192 contiguous bytes per row.  Q: 1024 8-float chunks, L = u * 512 + tid -> row L / 4, chunk L % 4.
-    uint32_t pg[6], pl[6];
+    // P by LDS-DMA: the buffer is 1536 16-byte chunks in [row][plane][slot] order; pass u, thread t writes chunk
+    // L = u * 256 + t (linear in the lane, as the DMA requires) and fetches source chunk slot ^ ((row >> 3) & 1)
+    uint32_t pg[6];
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
-        const int L = u * S::NT + tid, row = L / 12, within = L % 12;
+        const int L = u * S::NT + tid, row = L / 6, within = L % 6;
         long long r = prow0 + row;
         r = r < lp.rows ? r : lp.rows - 1;                                  // clamped (epilogues guard on the feature index)
-        pg[u] = (uint32_t)((r * lp.ksteps) * 192 + within * 16);
-        pl[u] = (uint32_t)x6_lds_off(within / 4, row, within % 4);
+        pg[u] = (uint32_t)((r * lp.ksteps) * 96 + (within >> 1) * 32 + (((within & 1) ^ ((row >> 3) & 1)) * 16));
     }
-    typename LoadQ::RowState qs[2];
-    const int qc = tid & 3;
+    auto dma_p = [&](int kt, int buf) {
+        const unsigned char* gb = reinterpret_cast<const unsigned char*>(lp.base) + (size_t)kt * 96;
+        unsigned char* lb = sP + buf * S::P_BYTES + (w * 64) * 16;          // wave-uniform; the hardware adds lane * 16
 #pragma unroll
-    for (int u = 0; u < 2; ++u) qs[u] = lq.row_state(qrow0 + u * 128 + (tid >> 2));
-    u32x4 rp[6];
-    f32x4 rq[4];
-    auto load_stage = [&](int kt) {
-        const unsigned char* gb = reinterpret_cast<const unsigned char*>(lp.base) + (size_t)kt * 192;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) rp[u] = *reinterpret_cast<const u32x4*>(gb + pg[u]);
-        const int k = kt * BK + qc * 8;
-        const bool v0 = lq.k_valid(k), v1 = lq.k_valid(k + 4);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            rq[2 * u] = v0 ? lq.load(qs[u], k) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rq[2 * u + 1] = v1 ? lq.load(qs[u], k + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int u = 0; u < 6; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + pg[u]),
+                                             (__attribute__((address_space(3))) void*)(lb + u * S::NT * 16), 16, 0, 0);
     };
-    // Q is double-buffered: its split + stores go to the other buffer BEFORE the barrier that ends a K-step (under the
-    // other waves' MFMAs); only the plain copies of the P planes sit between the two barriers
+    // Q through registers: thread t stages the 8 floats [c * 8, c * 8 + 8) of row t / 2 (c = t % 2)
+    const int qrow = tid >> 1, qc = tid & 1;
+    const typename LoadQ::RowState qs = lq.row_state(qrow0 + qrow);
+    const int qoff = qrow * 96 + ((qc ^ ((qrow >> 3) & 1)) * 16);
+    f32x4 rq[2];
+    auto load_q = [&](int kt) {
+        const int k = kt * S::BK16 + qc * 8;
+        rq[0] = lq.k_valid(k) ? lq.load(qs, k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        rq[1] = lq.k_valid(k + 4) ? lq.load(qs, k + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
     auto store_q = [&](int buf) {
-        unsigned char* dst = sQ + buf * 3 * S::PLANE_BYTES;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = u * 128 + (tid >> 2);
-            u32x4 h, m, l;
-            x6_split8(rq[2 * u], rq[2 * u + 1], h, m, l);
-            *reinterpret_cast<u32x4*>(dst + x6_lds_off(0, row, qc)) = h;
-            *reinterpret_cast<u32x4*>(dst + x6_lds_off(1, row, qc)) = m;
-            *reinterpret_cast<u32x4*>(dst + x6_lds_off(2, row, qc)) = l;
-        }
-    };
-    auto store_p = [&]() {
-#pragma unroll
-        for (int u = 0; u < 6; ++u) *reinterpret_cast<u32x4*>(sP + pl[u]) = rp[u];
+        unsigned char* dst = sQ + buf * S::Q_BYTES + qoff;
+        u32x4 h, m, l;
+        x6_split8(rq[0], rq[1], h, m, l);
+        *reinterpret_cast<u32x4*>(dst) = h;
+        *reinterpret_cast<u32x4*>(dst + 32) = m;
+        *reinterpret_cast<u32x4*>(dst + 64) = l;
     };
 
     Acc<S::TP, S::TQ, S::WP, S::WQ> acc;
@@ -446,46 +433,44 @@ __global__ __launch_bounds__(512, 1) void gemm_x6_kernel(PlaneRows lp, LoadQ lq,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
 
-    load_stage(0);
+    dma_p(0, 0);
+    load_q(0);
     store_q(0);
-    store_p();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int frow = lane & 31, fh = lane >> 5;
+    const int fbase = frow * 96 + ((fh ^ ((frow >> 3) & 1)) * 16);         // lane part of every fragment address
     for (int kt = 0; kt < ksteps; ++kt) {
+        const int buf = kt & 1;
         const bool more = kt + 1 < ksteps;
-        if (more) load_stage(kt + 1);
+        if (more) {
+            dma_p(kt + 1, buf ^ 1);
+            load_q(kt + 1);
+        }
+        const unsigned char* pa_base = sP + buf * S::P_BYTES + (wp * 128) * 96 + fbase;
+        const unsigned char* pb_base = sQ + buf * S::Q_BYTES + (wq * 64) * 96 + fbase;
+        bf16x8 b[S::TQ][3];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int chunk = 2 * s + fh;
-            bf16x8 b[S::TQ][3];
+        for (int j = 0; j < S::TQ; ++j)
 #pragma unroll
-            for (int j = 0; j < S::TQ; ++j)
+            for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const bf16x8*>(pb_base + j * 32 * 96 + p * 32);
+        // P plane h with Q planes l, m, h; P plane m with Q planes m, h; P plane l with Q plane h
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    b[j][p] = *reinterpret_cast<const bf16x8*>(sQ + (kt & 1) * 3 * S::PLANE_BYTES +
-                                                               x6_lds_off(p, wq * 64 + j * 32 + frow, chunk));
-            // P plane h with Q planes l, m, h; P plane m with Q planes m, h; P plane l with Q plane h
+        for (int pa = 0; pa < 3; ++pa) {
+            bf16x8 a[S::TP];
 #pragma unroll
-            for (int pa = 0; pa < 3; ++pa) {
-                bf16x8 a[S::TP];
+            for (int i = 0; i < S::TP; ++i) a[i] = *reinterpret_cast<const bf16x8*>(pa_base + i * 32 * 96 + pa * 32);
+#pragma unroll
+            for (int pb = 2 - pa; pb >= 0; --pb)
 #pragma unroll
                 for (int i = 0; i < S::TP; ++i)
-                    a[i] = *reinterpret_cast<const bf16x8*>(sP + x6_lds_off(pa, wp * 128 + i * 32 + frow, chunk));
 #pragma unroll
-                for (int pb = 2 - pa; pb >= 0; --pb)
-#pragma unroll
-                    for (int i = 0; i < S::TP; ++i)
-#pragma unroll
-                        for (int j = 0; j < S::TQ; ++j)
-                            acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j][pb], acc.v[i][j], 0, 0, 0);
-            }
+                    for (int j = 0; j < S::TQ; ++j)
+                        acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j][pb], acc.v[i][j], 0, 0, 0);
         }
-        if (more) store_q((kt + 1) & 1);
-        __syncthreads();               // every wave has read the P planes of this K-step (and the Q buffer of the last)
-        if (more) {
-            store_p();
-            __syncthreads();
-        }
+        if (more) store_q(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // my share of the next P planes has landed
+        __syncthreads();                   // step kt consumed by every wave; step kt+1's planes visible
     }
     epi(acc, smem);
 }
@@ -509,7 +494,7 @@ inline hipError_t launch_gemm_x6(const uint16_t* planes, int p_rows, const LoadQ
     tm.tiles_small = (p_rows + S::BP - 1) / S::BP;
     tm.tiles_big = (int)((q_rows + S::BQ - 1) / S::BQ);
     if (tm.tiles_small <= 0 || tm.tiles_big <= 0) return hipSuccess;
-    const int ksteps = K / BK;
+    const int ksteps = K / S::BK16;
     PlaneRows lp{planes, p_rows, ksteps};
     char tag[64];
     if (g_prof_on) snprintf(tag, sizeof(tag), "%s_%dx%d_x6", Epi::name, S::BP, S::BQ);

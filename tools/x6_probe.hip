@@ -50,7 +50,9 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& h,
     }
 }
 
-template <bool STORE>
+// MODE bits: 1 = store C, 2 = skip global loads after the first K-step, 4 = skip the split (store raw planes),
+// 8 = skip LDS fragment reads after the first K-step, 16 = skip the staging stores + second barrier
+template <int MODE>
 __global__ __launch_bounds__(NT, 1) void x6_kernel(const uint16_t* __restrict__ Wp,   // [N][K/32][3][32] bf16 planes
                                                    const float* __restrict__ X,       // [M][K] fp32
                                                    float* __restrict__ C, int M, int N, int K) {
@@ -94,7 +96,8 @@ __global__ __launch_bounds__(NT, 1) void x6_kernel(const uint16_t* __restrict__ 
         for (int u = 0; u < 2; ++u) {
             const int L = u * NT + tid, row = L / 4, c = L % 4;
             u32x4 h, m, l;
-            split8(rq[2 * u], rq[2 * u + 1], h, m, l);
+            if (MODE & 4) { h = __builtin_bit_cast(u32x4, rq[2 * u]); m = __builtin_bit_cast(u32x4, rq[2 * u + 1]); l = h; }
+            else split8(rq[2 * u], rq[2 * u + 1], h, m, l);
             *reinterpret_cast<u32x4*>(sQ + lds_off(0, row, c)) = h;
             *reinterpret_cast<u32x4*>(sQ + lds_off(1, row, c)) = m;
             *reinterpret_cast<u32x4*>(sQ + lds_off(2, row, c)) = l;
@@ -115,11 +118,13 @@ __global__ __launch_bounds__(NT, 1) void x6_kernel(const uint16_t* __restrict__ 
     const int frow = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < ksteps; ++kt) {
         const bool more = kt + 1 < ksteps;
-        if (more) load_stage(kt + 1);
+        if (more && !(MODE & 2)) load_stage(kt + 1);
+        bf16x8 b[2][3];
+        bf16x8 a3[3][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int chunk = 2 * s + fh;
-            bf16x8 b[2][3];
+            if (!(MODE & 8) || kt == 0)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -128,7 +133,8 @@ __global__ __launch_bounds__(NT, 1) void x6_kernel(const uint16_t* __restrict__ 
             // A plane h with B planes l, m, h; A plane m with B planes m, h; A plane l with B plane h (small terms first)
 #pragma unroll
             for (int pa = 0; pa < 3; ++pa) {
-                bf16x8 a[4];
+                bf16x8 (&a)[4] = a3[pa];
+                if (!(MODE & 8) || kt == 0)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     a[i] = *reinterpret_cast<const bf16x8*>(sP + lds_off(pa, wp * 128 + i * 32 + frow, chunk));
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(NT, 1) void x6_kernel(const uint16_t* __restrict__ 
             }
         }
         __syncthreads();
-        if (more) {
+        if (more && !(MODE & 16)) {
             store_stage();
             __syncthreads();
         }
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(NT, 1) void x6_kernel(const uint16_t* __restrict__ 
             for (int g = 0; g < 4; ++g) {
                 const int n0 = tn * BP + wp * 128 + i * 32 + 8 * g + 4 * fh;
                 f32x4 v{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                if (STORE || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(C + mrow * N + n0) = v;
+                if ((MODE & 1) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(C + mrow * N + n0) = v;
             }
     }
 }
@@ -193,27 +199,30 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dWp, hWp.data(), hWp.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(dC, 0, (size_t)M * N * 4));
     const size_t lds = 6 * PLANE_BYTES;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(x6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(x6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (M / BQ) * (N / BP);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 2; ++variant) {
-        auto launch = [&]() {
-            if (variant == 0) hipLaunchKernelGGL(x6_kernel<true>, dim3(grid), dim3(NT), lds, 0, dWp, dX, dC, M, N, K);
-            else hipLaunchKernelGGL(x6_kernel<false>, dim3(grid), dim3(NT), lds, 0, dWp, dX, dC, M, N, K);
-        };
-        for (int i = 0; i < 3; ++i) launch();
+    auto run = [&](auto kern, const char* label) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, 0, dWp, dX, dC, M, N, K);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        const int reps = 10;
-        for (int i = 0; i < reps; ++i) launch();
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, 0, dWp, dX, dC, M, N, K);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        printf("%s: %.3f ms  %.1f TFLOP/s fp32-equivalent (fp32 MFMA peak 157.3)\n", variant == 0 ? "store" : "sink ", ms,
-               2.0 * M * N * K / (ms * 1e-3) / 1e12);
-    }
+        printf("%-46s %.3f ms  %6.1f TFLOP/s fp32-equivalent\n", label, ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
+    };
+    run(x6_kernel<1>, "full, store");
+    run(x6_kernel<1>, "full, store (again)");
+    run(x6_kernel<0>, "full, sink");
+    run(x6_kernel<4>, "no split");
+    run(x6_kernel<2>, "no global loads");
+    run(x6_kernel<2 | 4>, "no global loads, no split");
+    run(x6_kernel<2 | 4 | 16>, "no loads/split/staging stores");
+    run(x6_kernel<2 | 4 | 16 | 8>, "MFMA only (1 barrier per K-step)");
+    run(x6_kernel<8>, "no LDS fragment reads, everything else");
     // accuracy: x6 vs fp64 and (for scale) an fp32 fma chain vs fp64, on a sample of outputs
-    hipLaunchKernelGGL(x6_kernel<true>, dim3(grid), dim3(NT), lds, 0, dWp, dX, dC, M, N, K);
+    hipLaunchKernelGGL(x6_kernel<1>, dim3(grid), dim3(NT), lds, 0, dWp, dX, dC, M, N, K);
     CK(hipDeviceSynchronize());
     std::vector<float> hC((size_t)1024 * N);
     CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
