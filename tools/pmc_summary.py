@@ -27,6 +27,10 @@ def short(name):
                "EpiFilter": "search_filter", "EpiStoreScores": "search_sample"}.get(e.group(1), e.group(1))
         gather = "_gather" if "EmbConcatRows" in name else ""
         return f"{epi}{gather}_{32 * wp * tp}x{32 * wq * tq}"
+    mx = re.search(r"gemm_x6_kernel<.*?amdrec::(Epi\w+)", name)
+    if mx:
+        epi = {"EpiLinearT": "linear", "EpiResidualLNT": "residual_ln", "EpiCrossT": "cross", "EpiL2NormT": "l2norm"}.get(mx.group(1), mx.group(1))
+        return f"{epi}_256x128_x6"
     if "scan_filter_kernel" in name:
         return "search_filter_stream128x512_bf16"
     return name.split("(")[0].replace("amdrec::", "").replace("void ", "")[:60]
