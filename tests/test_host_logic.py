@@ -110,3 +110,21 @@ def test_synthetic_criteo_and_preprocessor(tmp_path):
 
 def test_struct_sizes_are_stable():
     assert ctypes.sizeof(weights.TowerParams) % 8 == 0 and ctypes.sizeof(weights.RankerParams) % 8 == 0
+
+
+def test_split_planes_is_an_exact_three_way_bf16_split_in_kernel_layout():
+    """weights.split_planes (the host side of the x6 GEMM): h + m + l == w exactly, each plane is a bf16 (low 16 bits
+    of its fp32 pattern are zero), layout [out][ld/16][3][16]."""
+    from amdrec.weights import split_planes
+    rng = np.random.default_rng(3)
+    w = (rng.standard_normal((40, 64)) * np.exp(rng.uniform(-20, 20, (40, 64)))).astype(np.float32)
+    w[0, :4] = [0.0, -0.0, 1.0, -3.5]
+    pl = split_planes(w).view(np.uint16)
+    assert pl.shape == (40, 4, 3, 16)
+    back = (pl.astype(np.uint32) << 16).view(np.float32)                    # every plane as fp32
+    h, m, l = (back[:, :, i, :].reshape(40, 64) for i in range(3))
+    assert np.array_equal(h + m + l, w)                                     # exact (h + m is exact, + l is exact)
+    assert np.array_equal((h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64)).astype(np.float32), w)
+    # magnitudes shrink by >= 2^-8 per plane (8 significand bits each)
+    nz = w != 0
+    assert np.all(np.abs(m[nz]) <= np.abs(h[nz]) * 2.0 ** -7) and np.all(np.abs(l[nz]) <= np.abs(h[nz]) * 2.0 ** -15)
