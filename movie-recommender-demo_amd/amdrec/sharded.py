@@ -7,9 +7,10 @@ rows [offset_r, offset_r + n_r); weights and the ad-feature table are replicated
   1. every rank encodes the GLOBAL user batch (the tower is 0.26 GFLOP per 512 users - cheaper
      than broadcasting embeddings) and searches ITS shard for all users -> [B_g, k] scores and
      global positions;
-  2. ONE all-gather of a packed per-rank buffer [scores f32 | global positions i32] (8 B per
-     candidate; 2.05 MB per rank per 512 users x 500) - one fused collective instead of two; the
-     payload is latency-bound on xGMI, so no ring-sized bucketing is needed;
+  2. ONE collective on a packed buffer [scores f32 | global positions i32] (8 B per candidate): an all-to-all in
+     which every rank sends each peer only the lists of that peer's users (B*k*8 bytes in and out per rank whatever
+     the world size: 2 MB per 512 users x 500), or - when the batch does not divide - an all-gather of everything
+     (world x as much); the payload is latency-bound on xGMI, so no ring-sized bucketing is needed;
   3. rank r merges the world's lists for ITS contiguous slice of users (G*k -> k, exact, same
      order rule as the single-GPU search: the result is bit-identical to an unsharded search);
   4. rank r ranks its own users' candidates (data parallel) and selects their top-k.
@@ -81,10 +82,25 @@ def all_gather_bytes(out: torch.Tensor, inp: torch.Tensor, group=None):
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
+def all_to_all_bytes(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """all_to_all_single with equal splits; device tensors under a gloo group are staged through the host."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, h_in, group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+
+
 class ShardedRecommender:
     def __init__(self, rec, rank: int, world: int, shard_offset: int, group: Optional[dist.ProcessGroup] = None,
-                 engine=None):
-        self.rank, self.world, self.group = rank, world, group
+                 engine=None, exchange: str = "auto"):
+        """``exchange``: "all_to_all" - every rank sends each peer only the candidate lists of THAT peer's users
+        (B*k*8 bytes in and out per rank, independent of the world size; needs n_users % world == 0);
+        "all_gather" - every rank receives every list (world x as much); "auto" picks all_to_all when it applies."""
+        if exchange not in ("auto", "all_to_all", "all_gather"):
+            raise ValueError("exchange must be 'auto', 'all_to_all' or 'all_gather'")
+        self.rank, self.world, self.group, self.exchange = rank, world, group, exchange
         self.engine = engine if engine is not None else HipEngine(rec, shard_offset)
 
     @torch.no_grad()
@@ -94,13 +110,29 @@ class ShardedRecommender:
         uc, un = user_categorical, user_numerical
         B, k = uc.shape[0], stage1_k
         scores, pos = self.engine.local_search(uc, un, k)                     # [B,k] each
+        q0, nq = user_slice(B, self.rank, self.world)
+        if self.exchange == "all_to_all" and B % self.world:
+            raise ValueError("exchange='all_to_all' needs n_users divisible by the world size")
+        if self.exchange != "all_gather" and B % self.world == 0 and self.world > 1:
+            # destination d receives [scores of d's users | positions of d's users] from every rank
+            s_bytes, chunk = packed_layout(nq, k)
+            send = torch.empty(chunk * self.world, dtype=torch.uint8, device=scores.device)
+            sv = send.view(self.world, chunk)
+            sv[:, :s_bytes].view(torch.float32).copy_(scores.reshape(self.world, nq * k))
+            sv[:, s_bytes:].view(torch.int32).copy_(pos.reshape(self.world, nq * k))    # int64 -> int32 on the wire
+            recv = torch.empty_like(send)
+            all_to_all_bytes(recv, send, self.group)                          # ONE collective per step
+            cand_scores, cand_pos = self.engine.merge(recv, self.world, nq, k, 0, nq)
+            out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
+            out["candidate_scores"] = cand_scores
+            out["user_offset"] = q0
+            return out
         s_bytes, chunk = packed_layout(B, k)
         buf = torch.empty(chunk, dtype=torch.uint8, device=scores.device)
         buf[:B * k * 4].view(torch.float32).copy_(scores.reshape(-1))
         buf[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))        # int64 -> int32 on the wire
         gathered = torch.empty(chunk * self.world, dtype=torch.uint8, device=scores.device)
         all_gather_bytes(gathered, buf, self.group)                           # ONE collective per step
-        q0, nq = user_slice(B, self.rank, self.world)
         cand_scores, cand_pos = self.engine.merge(gathered, self.world, B, k, q0, nq)
         out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
         out["candidate_scores"] = cand_scores

@@ -58,7 +58,7 @@ class OracleEngine:
                 "tasks": list(oracle.ranker.TASKS), "candidate_ids": cand_pos}
 
 
-def _inputs():
+def _inputs(B=B):
     user, ad, nnum = cases.small_dims()
     tt_sd = synth.two_tower_state(user, ad, nnum, seed=41)
     rk_sd = synth.ranker_state(user, ad, nnum, seed=42, cross_scale=1.0 / 16)
@@ -68,17 +68,17 @@ def _inputs():
     return tt_sd, rk_sd, ad_table, corpus, uc, un
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, B=B, exchange="auto"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs()
+        tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(B)
         per = (N_ADS + world - 1) // world
         lo, hi = rank * per, min(N_ADS, (rank + 1) * per)
         eng = OracleEngine(tt_sd, rk_sd, corpus[lo:hi], lo, ad_table)
-        sr = ShardedRecommender(None, rank, world, lo, engine=eng)
+        sr = ShardedRecommender(None, rank, world, lo, engine=eng, exchange=exchange)
         out = sr.recommend_device(torch.from_numpy(uc), torch.from_numpy(un), TOPK, K1)
         q.put((rank, out["user_offset"], out["ad_ids"].numpy(), out["scores"].numpy(),
                out["candidate_ids"].numpy(), out["candidate_scores"].numpy()))
@@ -96,19 +96,22 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_pipeline_equals_unsharded_oracle():
+@pytest.mark.parametrize("B,exchange", [(7, "auto"),            # 7 users / 2 ranks: ragged slices -> all-gather
+                                        (8, "auto"),            # divisible -> all-to-all (each peer gets its users' lists)
+                                        (8, "all_gather")])
+def test_two_rank_sharded_pipeline_equals_unsharded_oracle(B, exchange):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, B, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in range(world)])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs()
+    tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(B)
     oidx = oracle.search.FlatIndex(256)
     oidx.add(corpus)
     ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
