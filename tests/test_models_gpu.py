@@ -128,11 +128,11 @@ def test_ranker_score_candidates_broadcast_and_gather():
         assert ok, (t, err)
 
 
-@pytest.mark.parametrize("cross", ["scaled", "randn"])
-def test_ranker_large_pass_on_the_split_bf16_gemm_matches_oracle_and_fp32_engine(cross):
+@pytest.mark.parametrize("name,cross", [("demo", "scaled"), ("demo", "randn"), ("ragged", "scaled")])
+def test_ranker_large_pass_on_the_split_bf16_gemm_matches_oracle_and_fp32_engine(name, cross):
     """Passes of more than 8192 rows run the error-compensated bf16-MFMA GEMM (gemm_engine 'bf16x6'): same tolerance
     against the oracle as the fp32-MFMA engine, and the two engines agree to fp32 rounding level."""
-    m, sd, (user, ad, nnum), _ = _ranker("demo", cross)
+    m, sd, (user, ad, nnum), _ = _ranker(name, cross)
     U, k, N = 24, 500, 30_000                                            # 12000 rows
     uc, un = synth.user_batch(user, nnum, U, seed=29)
     table = synth.ad_features(ad, N, seed=30)
