@@ -371,7 +371,10 @@ __device__ __forceinline__ void x6_split8(const f32x4& a, const f32x4& b, u32x4&
     }
 }
 
-template <class LoadQ, class Epi>
+// DBG (tools/x6v2_probe.hip only; 0 in the product, every test is `if constexpr`): 1 = no P DMA / Q loads after the
+// first K-step, 2 = no LDS fragment reads after the first K-step, 4 = no split / Q plane stores after the first
+// K-step, 8 = no barrier inside the K loop.
+template <class LoadQ, class Epi, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(PlaneRows lp, LoadQ lq, Epi epi, int ksteps, TileMap tm) {
     using S = ShapeX6;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -443,23 +446,28 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(PlaneRows lp, LoadQ lq,
     for (int kt = 0; kt < ksteps; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < ksteps;
-        if (more) {
+        if (more && !(DBG & 1)) {
             dma_p(kt + 1, buf ^ 1);
             load_q(kt + 1);
         }
-        const unsigned char* pa_base = sP + buf * S::P_BYTES + (wp * 128) * 96 + fbase;
-        const unsigned char* pb_base = sQ + buf * S::Q_BYTES + (wq * 64) * 96 + fbase;
+        const unsigned char* pa_base = sP + ((DBG & 1) ? 0 : buf) * S::P_BYTES + (wp * 128) * 96 + fbase;
+        const unsigned char* pb_base = sQ + ((DBG & 1) ? 0 : buf) * S::Q_BYTES + (wq * 64) * 96 + fbase;
         bf16x8 b[S::TQ][3];
+        bf16x8 a3[3][S::TP];
+        if (!(DBG & 2) || kt == 0) {
 #pragma unroll
-        for (int j = 0; j < S::TQ; ++j)
+            for (int j = 0; j < S::TQ; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const bf16x8*>(pb_base + j * 32 * 96 + p * 32);
+                for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const bf16x8*>(pb_base + j * 32 * 96 + p * 32);
+        }
         // P plane h with Q planes l, m, h; P plane m with Q planes m, h; P plane l with Q plane h
 #pragma unroll
         for (int pa = 0; pa < 3; ++pa) {
-            bf16x8 a[S::TP];
+            bf16x8 (&a)[S::TP] = a3[(DBG & 2) ? pa : 0];
+            if (!(DBG & 2) || kt == 0) {
 #pragma unroll
-            for (int i = 0; i < S::TP; ++i) a[i] = *reinterpret_cast<const bf16x8*>(pa_base + i * 32 * 96 + pa * 32);
+                for (int i = 0; i < S::TP; ++i) a[i] = *reinterpret_cast<const bf16x8*>(pa_base + i * 32 * 96 + pa * 32);
+            }
 #pragma unroll
             for (int pb = 2 - pa; pb >= 0; --pb)
 #pragma unroll
@@ -468,10 +476,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(PlaneRows lp, LoadQ lq,
                     for (int j = 0; j < S::TQ; ++j)
                         acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j][pb], acc.v[i][j], 0, 0, 0);
         }
-        if (more) store_q(buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // my share of the next P planes has landed
-        __syncthreads();                   // step kt consumed by every wave; step kt+1's planes visible
+        if (more && !(DBG & 4)) store_q(buf ^ 1);
+        if (!(DBG & 8)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // my share of the next P planes has landed
+            __syncthreads();               // step kt consumed by every wave; step kt+1's planes visible
+        }
     }
+    if (DBG & 8) __syncthreads();
     epi(acc, smem);
 }
 
