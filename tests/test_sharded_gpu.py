@@ -71,5 +71,13 @@ def test_sharded_recommender_single_rank_rccl_matches_pipeline():
         torch.cuda.synchronize()
         assert torch.equal(a["ad_ids"], b["ad_ids"]) and torch.equal(a["scores"], b["scores"])
         assert torch.equal(allr["ad_ids"], b["ad_ids"]) and torch.equal(allr["scores"], b["scores"])
+        # the RCCL entry points of the exchange on packed uint8 device buffers (world 1: both are a copy)
+        from amdrec.sharded import all_gather_bytes, all_to_all_bytes
+        src = torch.randint(0, 255, (4096,), dtype=torch.uint8, device="cuda")
+        d1, d2 = torch.empty_like(src), torch.empty_like(src)
+        all_to_all_bytes(d1, src)
+        all_gather_bytes(d2, src)
+        torch.cuda.synchronize()
+        assert torch.equal(d1, src) and torch.equal(d2, src)
     finally:
         dist.destroy_process_group()
