@@ -21,11 +21,12 @@
 // MFMA-bound into memory-bound; the result stays the exact fp32 one because
 //   * eps_q = EPS_REL * |q| * max_row|x| bounds |approx - exact| for every row (bf16 round-to-nearest of both
 //     operands: relative 2^-9 each; Cauchy-Schwarz; plus the fp32 accumulation slack),
-//   * finalize sorts the candidates by approximate score, keeps those with approx >= a_k - 2 eps (a_k = k-th
-//     largest approx; anything below is beaten by k rows), RE-SCORES them in fp32 from the fp32 corpus, sorts again,
+//   * finalize radix-selects a_k = the k-th largest approximate score, keeps the candidates with approx >= a_k - 2 eps
+//     (anything below is beaten by k rows), RE-SCORES them in fp32 from the fp32 corpus and sorts them,
 //   * and certifies: every row outside the list has approx < tau, i.e. exact < tau + eps; if the k-th re-scored
 //     value is >= tau + eps nothing outside can enter the top-k.  A query that fails the certificate (or the
 //     count test) goes to the same exact fp32 fix-up scan as before.
+// For dims 32 / 64 / 128 / 256 the corpus pass of this variant is scan_filter_kernel (below), not a generic GEMM tile.
 #include <type_traits>
 #include "gemm_core.hpp"
 #include "topk_utils.hpp"
