@@ -59,35 +59,30 @@ def build_models(device, seed=7):
     return tt.to(device).eval(), rk.to(device).eval(), (tt_sd, rk_sd), (user, ad, nnum)
 
 
-def device_corpus(n, dim, device, seed=1234, row0=0, rows=None):
-    """randn rows, L2-normalised, generated on the device in fixed 65536-row blocks so that any
-    shard [row0, row0+rows) of the same (n, seed) corpus is bit-identical on every rank."""
-    rows = n - row0 if rows is None else rows
-    out = torch.empty((rows, dim), dtype=torch.float32, device=device)
-    blk = 65536
-    b0, b1 = row0 // blk, (row0 + rows + blk - 1) // blk
-    for b in range(b0, b1):
-        g = torch.Generator(device=device)
-        g.manual_seed(seed * 1_000_003 + b)
-        x = torch.randn((blk, dim), generator=g, device=device, dtype=torch.float32)
-        x = x / x.norm(dim=1, keepdim=True).clamp_min(1e-30)
-        s, e = max(b * blk, row0), min((b + 1) * blk, row0 + rows, n)
-        if e > s:
-            out[s - row0:e - row0] = x[s - b * blk:e - b * blk]
-    return out
+def device_corpus(n, dim, device, seed=1234, row0=0, rows=None, kind="random"):
+    """The benchmark corpus (amdrec.devsynth): any shard of the same (n, seed) corpus is bit-identical on every rank."""
+    from amdrec import devsynth
+    if kind == "clustered":
+        return devsynth.device_clustered_corpus(n, dim, device, seed=seed, row0=row0, rows=rows)
+    return devsynth.device_corpus(n, dim, device, seed=seed, row0=row0, rows=rows)
 
 
-def pmc_traffic(tag):
+def pmc_traffic(tag, run_tags=()):
     """HBM bytes per launch of the kernel family behind a bench tag, from the committed PMC summary
     (profiles/rNN_pmc.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-    command, gfx950 x2 read correction applied - tools/pmc_summary.py).  None if no summary is committed."""
+    command, gfx950 x2 read correction applied - tools/pmc_summary.py).  None if no summary is committed, or if the
+    newest summary was taken on a different set of kernels than the ones this run launched (a stale file must not
+    be quoted: the summary lists `bench_tags`, compared with this run's profiling tags)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
         return None
     try:
-        k = json.load(open(files[-1]))["kernels"]
+        doc = json.load(open(files[-1]))
+        k = doc["kernels"]
     except Exception:
+        return None
+    if sorted(doc.get("bench_tags", [])) != sorted(run_tags):
         return None
     epi, shape = tag.rsplit("_", 1)
     fam = [v for name, v in k.items() if name in (tag, f"{epi}_gather_{shape}") and "hbm_bytes_per_launch" in v]
@@ -98,17 +93,18 @@ def pmc_traffic(tag):
             "source": os.path.basename(files[-1])}
 
 
-def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, n_users):
-    """The CPU oracle (port of the reference path) timed on this host's cores on a bounded
-    sample of the same workload: n_users users against the full 1M corpus."""
+def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, uc, un, n_users, user_chunk=32):
+    """The CPU oracle (port of the reference path) timed on this host's cores on a bounded sample of the same
+    workload: the FIRST n_users users of the GPU step's own batch against the full corpus, so that its output doubles
+    as a full-size parity check of the GPU step (parity_check).  The ranker leg is fed user_chunk users x 500
+    candidate rows per forward (the reference loops 500-row forwards, inference.py:310-317: the 8-core survey probe
+    of that form gave 38 recs/s)."""
     import oracle
-    from amdrec import synth
-    user, ad, nnum = dims
     idx = oracle.search.FlatIndex(DIM)
     idx.add(corpus_cpu)                                   # index build is not timed (nor is it on the GPU)
-    uc, un = synth.user_batch(user, nnum, n_users, seed=4242)
     t0 = time.time()
-    oracle.pipeline.recommend(tt_sd, rk_sd, idx, ad_table_cpu, uc, un, TOP_K, STAGE1_K)
+    ref = oracle.pipeline.recommend(tt_sd, rk_sd, idx, ad_table_cpu, uc[:n_users], un[:n_users], TOP_K, STAGE1_K,
+                                    user_chunk=user_chunk)
     dt = time.time() - t0
     try:
         from threadpoolctl import threadpool_info
@@ -119,9 +115,44 @@ def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, n_users):
         threads = min(threads, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    return {"value": n_users / dt, "unit": "recs/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n_users} users x 1M ads end-to-end through oracle/ (numpy fp32), {dt:.1f}s; "
-                      "faiss unavailable - numpy restatement"}
+    return {"value": round(n_users / dt, 2), "unit": "recs/s", "cores": int(threads), "kind": "port",
+            "sample": f"the first {n_users} users of the timed batch x {len(corpus_cpu)} ads end-to-end through oracle/ "
+                      f"(numpy fp32 BLAS, {threads} threads, ranker fed {user_chunk} users x {STAGE1_K} rows per forward), "
+                      f"{dt:.1f}s; faiss unavailable - numpy restatement of IndexFlatIP"}, ref
+
+
+def parity_check(ref, out, n_users):
+    """Full-size end-to-end check of the timed GPU step against the oracle run of cpu_baseline (same users, same
+    corpus): stage-1 candidate sets (tolerance-aware), ranker logits on the common candidates
+    against the STRICT rule |d| <= 1e-4 * max(1, |logit|), and the final top-10."""
+    import oracle
+    cand = out["candidate_ids"][:n_users].cpu().numpy()
+    cs = out["candidate_scores"][:n_users].cpu().numpy()
+    B_all = out["candidate_ids"].shape[0]
+    logits = out["logits"].cpu().numpy().reshape(3, B_all, STAGE1_K)
+    ids = out["ad_ids"][:n_users].cpu().numpy()
+    topk_ok, worst, top10_same, top10_ok = True, 0.0, 0, True
+    for b in range(n_users):
+        try:
+            oracle.search.check_topk(ref[b]["candidate_scores"][None], ref[b]["candidate_ids"][None], cs[b][None],
+                                     cand[b][None], tau=1e-5, score_tol=1e-6)
+        except AssertionError:
+            topk_ok = False
+        pos = {int(i): j for j, i in enumerate(ref[b]["candidate_ids"])}
+        common = [j for j, i in enumerate(cand[b]) if int(i) in pos]
+        sel = np.array([pos[int(cand[b][j])] for j in common])
+        for ti, t in enumerate(oracle.ranker.TASKS):
+            r = ref[b]["logits"][t][sel].astype(np.float64)
+            err = np.abs(logits[ti, b][common].astype(np.float64) - r)
+            worst = max(worst, float((err / (1e-4 * np.maximum(1.0, np.abs(r)))).max()))
+        # top-10: the GPU's winners must be the winners of its OWN logits (selection exact), and equal the oracle's
+        # unless a winner sits within the logit tolerance of the 10th place
+        own = cand[b][oracle.pipeline.select_top(logits[0, b], TOP_K)]
+        top10_ok = top10_ok and bool(np.array_equal(own, ids[b]))
+        top10_same += int(set(ids[b].tolist()) == set(ref[b]["ad_ids"]))
+    return {"users": n_users, "topk_set_ok": topk_ok, "max_logit_err_over_bound": round(worst, 5),
+            "logit_bound": "1e-4*max(1,|logit|) (strict SURVEY 8a rule, no batch-scale escape)",
+            "top10_selection_exact": top10_ok, "top10_equal_to_oracle_frac": round(top10_same / max(n_users, 1), 4)}
 
 
 def main():
@@ -131,7 +162,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=192)
-    ap.add_argument("--sweep", action="store_true", help="also print the search-only B sweep (stderr)")
+    ap.add_argument("--sweep", action="store_true", help="also print the end-to-end latency sweep by batch (stderr)")
+    ap.add_argument("--no-search-sweep", action="store_true",
+                    help="skip the search-only B sweep that fills the line's `search.sweep` (< 1 s)")
+    ap.add_argument("--corpus", choices=["random", "clustered"], default=None,
+                    help="synthetic corpus: randn unit rows (the reference benchmark's, default for flat) or a "
+                         "clustered one (default for ivf: an inverted file needs structure to exploit)")
     ap.add_argument("--ads", type=int, default=N_ADS, help="corpus size (configs[3]: 10000000)")
     ap.add_argument("--index", choices=["flat", "ivf"], default="flat", help="configs[4]: ivf")
     ap.add_argument("--nlist", type=int, default=4096, help="IVF lists over the WHOLE corpus (split over the ranks)")
@@ -167,7 +203,8 @@ def main():
     user, ad, nnum = dims
     per = (n_ads + world - 1) // world
     row0, rows = rank * per, max(0, min(per, n_ads - rank * per))
-    shard = device_corpus(n_ads, DIM, device, row0=row0, rows=rows)
+    corpus_kind = args.corpus or ("clustered" if args.index == "ivf" else "random")
+    shard = device_corpus(n_ads, DIM, device, row0=row0, rows=rows, kind=corpus_kind)
     if args.index == "ivf":
         # each rank is an independent IVF index over its rows: nlist/world lists, nprobe/world probes per rank
         index = FAISSIndex(DIM, index_type="IVF", nlist=max(1, args.nlist // world),
@@ -203,11 +240,17 @@ def main():
         step()
     barrier()
     _lib.profile_enable(True)                # HIP events around every GEMM launch, on the launch stream
+    # per-step HIP events on the launch stream (torch's current stream IS the stream every kernel is enqueued on,
+    # _lib.stream_ptr): median / p95 of the step time
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         out = step()
+    marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     prof = _lib.profile_report()
     _lib.profile_enable(False)
     if world > 1:
@@ -226,7 +269,7 @@ def main():
             name, p = dom
             avg_ms = p["total_ms"] / p["launches"]
             achieved = p["flops"] / p["launches"] / (avg_ms * 1e-3) / 1e12
-            tr = pmc_traffic(name)
+            tr = pmc_traffic(name, list(prof))
             x6 = name.endswith("_x6")       # fp32 GEMM computed as 6 bf16-MFMA products per MAC (exact 3-way split)
             peak = X6_PEAK_TFLOPS if x6 else FP32_PEAK_TFLOPS
             roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
@@ -256,17 +299,23 @@ def main():
                       "note": ("filter = one pass over the bf16 corpus; B=512 queries per pass, intensity 512 FLOP/B vs "
                                "bf16 ridge 312: compute-side bound (vector issue + bf16 MFMA), see DESIGN.md section 6" if mixed else
                                "B=512 per corpus pass is fp32-FLOP bound (intensity 255 FLOP/B vs ridge 19.7)")}
-        cpu = None
+        if search is not None and not args.no_search_sweep and world == 1 and args.index == "flat":
+            search["sweep"] = search_sweep(index, device)
+        cpu, parity = None, None
         if not args.no_cpu_baseline and world == 1:
             corpus_cpu = index._xb[:index._n].cpu().numpy()
-            cpu = cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table.cpu().numpy(), args.cpu_users)
-            if n_ads != N_ADS:
-                cpu["sample"] = cpu["sample"].replace("1M ads", f"{n_ads} ads")
+            n_cpu = min(args.cpu_users, B_global)
+            cpu, ref = cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table.cpu().numpy(), uc_np, un_np, n_cpu)
+            if args.index == "flat":            # the oracle index is exact: only the exact engine is comparable
+                parity = parity_check(ref, out, n_cpu)
         default_cfg = n_ads == N_ADS and args.index == "flat"
         line = {"metric": "end-to-end recs/sec (1M ads d=256, top-500->10)" if default_cfg else
                           f"end-to-end recs/sec ({n_ads} ads d=256, {args.index}, top-500->10)", "value": round(value, 1),
                 "unit": "recs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": round(ms_step, 3),
+                "step_ms_median": round(step_ms[len(step_ms) // 2], 3),
+                "step_ms_p95": round(step_ms[min(len(step_ms) - 1, int(np.ceil(0.95 * len(step_ms))) - 1)], 3),
+                "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "arithmetic": ("fp32 in / fp32 out everywhere; ranker GEMMs of > 8192 rows: operands split exactly into 3 "
                                "bf16 planes, 6 bf16-MFMA products per MAC, fp32 accumulate (error at the fp32 fma-chain "
@@ -279,7 +328,7 @@ def main():
                            "n_ads": n_ads, "dim": DIM, "users_per_step": B_global, "stage1_k": STAGE1_K,
                            "top_k": TOP_K, "corpus_rows_per_gpu": rows,
                            "parallelism": f"corpus row-sharded x{world}, ranker data-parallel over users"},
-                "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "search": search}
+                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "kernels": kernels, "search": search}
         print(json.dumps(line), flush=True)
     if flat_ref is not None and world == 1 and rank == 0:
         emb = tt.get_user_embeddings(uc, un)
@@ -290,7 +339,6 @@ def main():
         print(json.dumps({"ivf_recall_at_500_vs_flat": round(rec_at_k, 4), "nlist": index.nlist,
                           "nprobe": index.nprobe, "n_ads": n_ads}), file=sys.stderr, flush=True)
     if args.sweep and rank == 0 and world == 1:
-        search_sweep(index, device)
         latency_sweep(rec, uc, un, device)
     if world > 1:
         dist.barrier()
@@ -329,37 +377,49 @@ def latency_sweep(rec, uc, un, device, reps=30):
 
 
 def search_sweep(index, device, reps=20):
-    """Search-only sweep over queries per corpus pass: achieved algorithmic HBM GB/s
-    and fp32 TFLOP/s of the whole search call (sample + threshold + filter + finalize)."""
-    if index.index_type != "Flat":
-        return
+    """Search-only sweep over queries per corpus pass: achieved algorithmic HBM GB/s and
+    fp32-equivalent TFLOP/s of the WHOLE search call (sample + threshold + corpus pass + finalize), HIP events on the
+    launch stream; plus the corpus pass alone from the library's per-launch events (`pass_ms`).  B <= 32 is where HBM
+    binds (bf16 shadow: ridge ~300 queries per pass), B = 512 is the benchmark's batch."""
+    from amdrec import _lib
     n = index._n
     g = torch.Generator(device=device)
     g.manual_seed(5)
     q = torch.randn((512, DIM), generator=g, device=device)
     q = q / q.norm(dim=1, keepdim=True)
+    eb = 2 if getattr(index, "_mixed", False) else 4
     rows = []
     for B in (1, 8, 32, 128, 512):
         qq = q[:B].contiguous()
         for _ in range(3):
             index.search_device(qq, STAGE1_K, normalize=False)
         torch.cuda.synchronize(device)
+        _lib.profile_enable(True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
             index.search_device(qq, STAGE1_K, normalize=False)
         e1.record()
         torch.cuda.synchronize(device)
+        prof = _lib.profile_report()
+        _lib.profile_enable(False)
         ms = e0.elapsed_time(e1) / reps
         # one corpus pass (bf16 shadow when the index runs the mixed search) + the fp32 rows of the k results
-        eb = 2 if getattr(index, "_mixed", False) else 4
         alg_bytes = n * DIM * eb + B * DIM * 4 + B * STAGE1_K * 12 + (B * STAGE1_K * DIM * 4 if eb == 2 else 0)
         flops = 2.0 * B * n * DIM
-        rows.append({"B": B, "ms": round(ms, 4), "qps": round(B / ms * 1e3, 1),
-                     "alg_GBps": round(alg_bytes / ms / 1e6, 1), "hbm_frac": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                     "tflops": round(flops / ms / 1e9, 2), "fp32_frac": round(flops / ms / 1e9 / FP32_PEAK_TFLOPS, 4)})
-    print(json.dumps({f"search_sweep_{n}_k500": rows, "engine": "bf16+fp32 rescore" if eb == 2 else "fp32"}),
-          file=sys.stderr, flush=True)
+        row = {"B": B, "ms": round(ms, 4), "qps": round(B / ms * 1e3, 1),
+               "alg_GBps": round(alg_bytes / ms / 1e6, 1), "hbm_frac": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+               "tflops": round(flops / ms / 1e9, 2)}
+        for tag, v in prof.items():
+            if tag.startswith("search_filter") and v["launches"]:
+                pm = v["total_ms"] / v["launches"]
+                row["pass_ms"] = round(pm, 4)
+                row["pass_hbm_frac"] = round((n * DIM * eb + B * DIM * eb) / pm / 1e6 / HBM_PEAK_GBS, 4)
+            elif tag.startswith("search_") and v["launches"]:
+                row[tag.replace("search_", "") + "_ms"] = round(v["total_ms"] / v["launches"], 4)
+        rows.append(row)
+    return {"corpus_rows": n, "k": STAGE1_K, "engine": "bf16 filter + fp32 rescore" if eb == 2 else "fp32",
+            "rows": rows}
 
 
 if __name__ == "__main__":

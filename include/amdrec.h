@@ -49,7 +49,7 @@ int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld_corpus, in
 /* Mixed-precision form of the same search (same result contract: the exact fp32 top-k).  The sample and filter
  * passes read `corpus_bf16`, a bf16 (round-to-nearest) copy of the corpus made by amdrec_bf16_rows, with the bf16
  * MFMA; candidates are re-scored in fp32 from `corpus` and the result is certified against the error bound
- * eps = (2^-8 + ...) * |query| * max_norm[0]  (max_norm: device float = the largest row norm of the corpus, as
+ * eps = (2^-7 + 2^-16 + 2*dim*2^-24) * |query| * max_norm[0]  (bf16 unit roundoff 2^-8 on both operands)  (max_norm: device float = the largest row norm of the corpus, as
  * accumulated by amdrec_bf16_rows); uncertified queries take the exact fp32 fix-up scan.  dim % 8 == 0.
  * Turns the filter pass from fp32-MFMA-bound into memory-bound (half the bytes, 16x the MFMA rate). */
 int amdrec_bf16_rows(const float* x, int64_t rows, int64_t ld, int dim, uint16_t* out /*[rows][ld_out] bf16*/,

@@ -91,6 +91,14 @@ def ptr(t):
 
 
 def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on ``device`` - and make ``device`` the calling thread's current HIP
+    device: the C entry points launch kernels, set function attributes and memset on the CURRENT device (amdrec.h),
+    so a tensor on cuda:N (N != 0), or a call from a fresh thread (whose current device is 0), must switch first.
+    Every binding call site evaluates this right before the C call."""
+    if device is not None:
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -29,6 +29,29 @@ _MAGIC = b"AMDRECIX1"
 INDEX_TYPES = ("Flat", "IVF", "IVFPQ", "HNSW")
 
 
+def _encode_id(x):
+    """JSON form of one arbitrary ad id (the reference pickles id_map, faiss_retrieval.py:208-218; this format never
+    unpickles): [tag, value] with tag i / f / s / n.  Other types are refused at save time."""
+    if isinstance(x, (bool, np.bool_)):
+        raise TypeError("ad ids of type bool cannot be saved; use int or str")
+    if isinstance(x, (int, np.integer)):
+        return ["i", int(x)]
+    if isinstance(x, (float, np.floating)):
+        return ["f", float(x)]
+    if isinstance(x, str):
+        return ["s", x]
+    if x is None:
+        return ["n", None]
+    raise TypeError(f"ad ids of type {type(x).__name__} cannot be saved; use int, float, str or None")
+
+
+def _decode_id(e):
+    if isinstance(e, str):            # files written by the round-1 format (ids stringified)
+        return e
+    tag, v = e
+    return {"i": int, "f": float, "s": str, "n": lambda _: None}[tag](v)
+
+
 class _Handle:
     """The attributes of a faiss index object that the reference touches
     (``index.ntotal``, ``index.is_trained``, ``index.nprobe``: faiss_retrieval.py:90, :127, :150)."""
@@ -291,7 +314,7 @@ class FAISSIndex:
                   "nprobe": self.nprobe, "ntotal": self._n, "identity_ids": self._identity,
                   "arrays": [{"name": n, "dtype": str(a.dtype), "shape": list(a.shape)} for n, a in arrays]}
         if self._host_ids is not None:
-            header["host_ids"] = [str(x) for x in self._host_ids]
+            header["host_ids"] = [_encode_id(x) for x in self._host_ids]     # typed: ids round-trip as what they were
         hj = json.dumps(header).encode()
         with open(filepath, "wb") as f:
             f.write(_MAGIC)
@@ -327,7 +350,8 @@ class FAISSIndex:
         self._n = n
         self._shadow_rows(0, n)
         self._identity = header["identity_ids"]
-        self._host_ids = header.get("host_ids")
+        hid = header.get("host_ids")
+        self._host_ids = None if hid is None else [_decode_id(x) for x in hid]
         if self.index_type == "IVF":
             from . import ivf
             self._ivf = ivf.IVFState.from_arrays(arrays, self.device)

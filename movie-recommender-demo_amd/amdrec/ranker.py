@@ -85,6 +85,13 @@ class TransformerRanker(nn.Module):
         # three bf16 planes, six products per MAC, fp32 accumulate - fp32-level error); "fp32" = fp32 MFMA everywhere
         self.gemm_engine = "bf16x6"
 
+    ENGINES = ("bf16x6", "fp32")
+    SMALL_ROWS = 8192       # passes of at most this many rows always run the fp32-MFMA small shapes (csrc/layers.hip)
+
+    def gemm_engine_for(self, rows: int) -> str:
+        """The engine a pass of ``rows`` rows actually runs on."""
+        return self.gemm_engine if rows > self.SMALL_ROWS else "fp32"
+
     # -- packing ----------------------------------------------------------------------
     def invalidate(self):
         self._packed = None

@@ -68,6 +68,20 @@ __host__ __device__ inline uint32_t key_pos(unsigned long long k) { return ~(uin
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// hipFuncSetAttribute applies to the CURRENT device only, so "done once" must be tracked per device (a process may
+// drive several GPUs; a benign race between threads sets an attribute twice).
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool pending() const {
+        int d = 0;
+        return hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64 || !done[d];
+    }
+    void mark() {
+        int d = 0;
+        if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) done[d] = true;
+    }
+};
+
 // ---- optional per-launch timing (amdrec_profile_*): HIP events recorded on the launch stream
 // around each GEMM launch, accumulated per kernel tag.  Off by default (zero cost).
 struct ProfScope {

@@ -295,12 +295,12 @@ inline hipError_t launch_gemm(const LoadP& lp, const LoadQ& lq, const Epi& epi, 
     // dynamic LDS = the larger of the staging tiles and what the epilogue carves out of the same array
     constexpr size_t lds_bytes = S::LDS_BYTES > Epi::lds_bytes(S::NT / 64) ? S::LDS_BYTES : Epi::lds_bytes(S::NT / 64);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;   // per instantiation
+    if (attr_done.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done.mark();
     }
     TileMap tm;
     int tiles_p = (int)((p_rows + S::BP - 1) / S::BP), tiles_q = (int)((q_rows + S::BQ - 1) / S::BQ);
@@ -494,12 +494,12 @@ inline hipError_t launch_gemm_x6(const uint16_t* planes, int p_rows, const LoadQ
     auto kern = gemm_x6_kernel<LoadQ, Epi>;
     constexpr size_t lds_bytes = S::LDS_BYTES > Epi::lds_bytes(S::NT / 64) ? S::LDS_BYTES : Epi::lds_bytes(S::NT / 64);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;   // per instantiation
+    if (attr_done.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done.mark();
     }
     TileMap tm;
     tm.tiles_small = (p_rows + S::BP - 1) / S::BP;

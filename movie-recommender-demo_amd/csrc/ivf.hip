@@ -233,11 +233,11 @@ extern "C" int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, 
     REQUIRE(lists && row_pos && list_off && queries && group_off && qtile_prefix && pair_query && pair_probe &&
                 pool_base && pool_keys, "null pointer");
     REQUIRE(ld % 4 == 0 && ld >= dim && ld_queries >= dim && ld_queries % 4 == 0, "bad leading dimension");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_group_scan_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ShapeIvf::LDS_BYTES));
-        attr_done = true;
+        attr_done.mark();
     }
     const unsigned gx = (unsigned)((max_list_rows + ShapeIvf::BQ - 1) / ShapeIvf::BQ);
     hipLaunchKernelGGL(ivf_group_scan_kernel, dim3(gx, (unsigned)qtile_bound), dim3(ShapeIvf::NT), ShapeIvf::LDS_BYTES,

@@ -20,7 +20,8 @@
 // queries with v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, half the HBM bytes), which turns the filter from
 // MFMA-bound into memory-bound; the result stays the exact fp32 one because
 //   * eps_q = EPS_REL * |q| * max_row|x| bounds |approx - exact| for every row (bf16 round-to-nearest of both
-//     operands: relative 2^-9 each; Cauchy-Schwarz; plus the fp32 accumulation slack),
+//     operands: bf16 keeps 8 significant bits, unit roundoff u = 2^-8 each, so a product is off by at most
+//     2u + u^2 = 0.00783 of |q_i x_i|; Cauchy-Schwarz over the row; plus the fp32 accumulation slack),
 //   * finalize radix-selects a_k = the k-th largest approximate score, keeps the candidates with approx >= a_k - 2 eps
 //     (anything below is beaten by k rows), RE-SCORES them in fp32 from the fp32 corpus and sorts them,
 //   * and certifies: every row outside the list has approx < tau, i.e. exact < tau + eps; if the k-th re-scored
@@ -193,7 +194,8 @@ __global__ __launch_bounds__(512) void fixup_scan_kernel(const float* X, long lo
     __shared__ __attribute__((aligned(16))) float qv[2048];
     __shared__ unsigned long long thr;
     __shared__ int count;
-    const int q = blockIdx.y, s = blockIdx.x;
+    // 1-D grid (query-major): gridDim.y is limited to 65535 but nq may reach 2^24
+    const int q = blockIdx.x / nslices, s = blockIdx.x - q * nslices;
     if (!fail[q]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int NW = 8, U = 8;
@@ -523,12 +525,12 @@ static hipError_t launch_scan(const uint16_t* X16, long long ld16, long long nro
     auto kern = scan_filter_kernel<KS>;
     constexpr size_t lds_bytes = 2ull * SCAN_ROWS * 2 * KS * 16 + SCAN_HIT_BYTES;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done.mark();
     }
     const long long ntiles = (nrows + SCAN_ROWS - 1) / SCAN_ROWS;
     const int ny = (nq + SCAN_QGROUP - 1) / SCAN_QGROUP;
@@ -571,9 +573,12 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const float* x, long lon
     }
 }
 
-// |approx - exact| <= EPS_REL(d) * |q| * max|x|: 2u + u^2 with u = 2^-9 (bf16 RN of both operands) = 0.0039101,
-// rounded up, plus 2 d 2^-24 for the two fp32 accumulations being compared.
-__device__ __forceinline__ float eps_rel(int d) { return 0.00392f + (float)d * 1.2e-7f; }
+// |approx - exact| <= EPS_REL(d) * |q| * max|x|: bf16 has 8 significant bits, so round-to-nearest of an operand is a
+// relative error of at most u = 2^-8; both operands rounded: (1 + u)^2 - 1 = 2u + u^2 = 0.0078278 per product, rounded
+// up, and sum_i |q_i x_i| <= |q| |x| (Cauchy-Schwarz); plus 2 d 2^-24 for the two fp32 accumulations being compared.
+// (Round 1 used u = 2^-9, half the true bound: tests/test_search_gpu.py::test_mixed_worst_case_rounding holds the
+// input that exceeds that value.)
+__device__ __forceinline__ float eps_rel(int d) { return 0.00783f + (float)d * 1.2e-7f; }
 
 // step 4 of the mixed-precision search: select a_k -> prune -> fp32 re-score -> exact sort -> certificate.
 // The candidate keys (<= 16 per thread) stay in registers for the selection: a 3-pass radix select of the k-th
@@ -761,6 +766,7 @@ static hipError_t run_passes(const float* X, long long ldx, long long nrows, int
         EpiStoreScores es{S_, pl.n_sample, nq, pl.n_sample, lps};
         hipError_t e = launch_gemm<S, false>(lps, lq, es, d, pl.n_sample, nq, st, d_alg);
         if (e != hipSuccess) return e;
+        ProfScope prof("search_threshold", 0.0, 4.0 * (double)nq * (double)pl.n_sample, st);
         hipLaunchKernelGGL(sample_threshold_kernel, dim3(nq), dim3(THR_NT), 0, st, S_, pl.n_sample, pl.n_sample,
                            pl.rank, tau);
     } else {
@@ -786,11 +792,11 @@ extern "C" int amdrec_topk_merge(const float* scores, const int32_t* pos, int n_
     REQUIRE(scores && pos && out_scores && out_pos, "null pointer");
     int P = 2;
     while (P < n_lists * k) P <<= 1;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
-        attr_done = true;
+        attr_done.mark();
     }
     hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(512), (size_t)P * 8,
                        reinterpret_cast<hipStream_t>(stream), (const char*)scores, (const char*)pos, n_lists,
@@ -843,19 +849,19 @@ extern "C" int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld
         else               e = run_passes<Shape<4, 1, 2, 1>>(corpus, ld_corpus, nrows, dim, queries, ld_queries, (int)nq, pl, ws, st);
         HIP_TRY(e);
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_merge_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
-        attr_done = true;
+        attr_done.mark();
     }
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + pl.off_cand);
     unsigned long long* fix = reinterpret_cast<unsigned long long*>(ws + pl.off_fix);
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, cand, cnt, CAND_CAP, k,
                        (long long)nrows, fail, out_scores, (long long*)out_pos, (long long)pos_offset);
-    hipLaunchKernelGGL(fixup_scan_kernel, dim3(pl.nslices, (unsigned)nq), dim3(512), 0, st, corpus,
+    hipLaunchKernelGGL(fixup_scan_kernel, dim3((unsigned)(pl.nslices * nq)), dim3(512), 0, st, corpus,
                        (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, k,
                        pl.nslices, fix);
     hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, fix, fail, k,
@@ -947,21 +953,25 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
         }
     }
     const size_t fin_lds = (size_t)CAND_CAP * 8 + (size_t)dim * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_mixed_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_merge_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
-        attr_done = true;
+        attr_done.mark();
     }
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + pl.off_cand);
     unsigned long long* fix = reinterpret_cast<unsigned long long*>(ws + pl.off_fix);
     const float* tau = reinterpret_cast<const float*>(ws + pl.off_tau);
-    hipLaunchKernelGGL(finalize_mixed_kernel, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, cnt, CAND_CAP, k,
-                       (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries,
-                       (long long)ld_queries, fail, out_scores, (long long*)out_pos, (long long)pos_offset);
-    hipLaunchKernelGGL(fixup_scan_kernel, dim3(pl.nslices, (unsigned)nq), dim3(512), 0, st, corpus,
+    {
+        ProfScope prof("search_finalize_mixed", 0.0, 0.0, st);
+        hipLaunchKernelGGL(finalize_mixed_kernel, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, cnt, CAND_CAP, k,
+                           (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries,
+                           (long long)ld_queries, fail, out_scores, (long long*)out_pos, (long long)pos_offset);
+    }
+    ProfScope prof_fix("search_fixup", 0.0, 0.0, st);
+    hipLaunchKernelGGL(fixup_scan_kernel, dim3((unsigned)(pl.nslices * nq)), dim3(512), 0, st, corpus,
                        (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, k,
                        pl.nslices, fix);
     hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, fix, fail, k,

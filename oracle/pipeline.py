@@ -34,24 +34,32 @@ def select_top(logits, top_k):
 
 
 def recommend(tt_sd, rk_sd, index: "search.FlatIndex", ad_cat_table, user_cat, user_num,
-              top_k=10, stage1_k=500):
-    """Batch version: user_cat [B,6], user_num [B,13] -> list of result dicts."""
+              top_k=10, stage1_k=500, user_chunk=1):
+    """Batch version: user_cat [B,6], user_num [B,13] -> list of result dicts.
+    ``user_chunk``: users whose candidate rows go through the ranker in ONE forward (the reference's
+    batch_recommend is a serial loop of 500-row forwards, inference.py:310-317; rows are independent, so chunking
+    only changes how well the CPU's BLAS is fed - used by bench.py's cpu_baseline leg)."""
     user_cat = np.asarray(user_cat)
     user_num = np.asarray(user_num, dtype=np.float32)
     emb = towers.user_tower(tt_sd, user_cat, user_num)
     cand_ids, cand_scores = index.search(emb, k=stage1_k)
     out = []
-    for b in range(user_cat.shape[0]):
-        ids = cand_ids[b]
+    B = user_cat.shape[0]
+    for b0 in range(0, B, max(1, user_chunk)):
+        b1 = min(B, b0 + max(1, user_chunk))
+        kk = cand_ids.shape[1]
         logits = ranker.forward(rk_sd,
-                                np.repeat(user_cat[b:b + 1], len(ids), axis=0),
-                                ad_cat_table[ids],
-                                np.repeat(user_num[b:b + 1], len(ids), axis=0))
-        top = select_top(logits["ctr"], top_k)
-        out.append({
-            "ad_ids": ids[top].tolist(),
-            "candidate_ids": ids, "candidate_scores": cand_scores[b],
-            "logits": {t: logits[t] for t in ranker.TASKS},
-            "scores": {t: sigmoid(logits[t][top]).tolist() for t in ranker.TASKS},
-        })
+                                np.repeat(user_cat[b0:b1], kk, axis=0),
+                                ad_cat_table[cand_ids[b0:b1].reshape(-1)],
+                                np.repeat(user_num[b0:b1], kk, axis=0))
+        for b in range(b0, b1):
+            ids = cand_ids[b]
+            lg = {t: logits[t][(b - b0) * kk:(b - b0 + 1) * kk] for t in ranker.TASKS}
+            top = select_top(lg["ctr"], top_k)
+            out.append({
+                "ad_ids": ids[top].tolist(),
+                "candidate_ids": ids, "candidate_scores": cand_scores[b],
+                "logits": lg,
+                "scores": {t: sigmoid(lg[t][top]).tolist() for t in ranker.TASKS},
+            })
     return out

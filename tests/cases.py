@@ -38,7 +38,8 @@ def ranker_case(name, cross):
     return user, ad, nnum, sd, batches
 
 
-LOGIT_SCALE_RTOL = 1e-5  # ... or |d| <= LOGIT_SCALE_RTOL * max|logit| over the batch
+LOGIT_SCALE_RTOL = 1e-5  # randn fixtures only: ... or |d| <= LOGIT_SCALE_RTOL * max|logit| over the batch
+LOGIT_STRICT_RTOL = 1e-5  # scaled fixtures (the benchmark's weights): |d| <= 1e-5 * max(1, |logit|), 10x inside SURVEY 8a
 
 
 def logit_scale(ref_dict):
@@ -48,17 +49,25 @@ def logit_scale(ref_dict):
     return max(float(np.abs(np.asarray(v)).max()) if np.asarray(v).size else 0.0 for v in ref_dict.values())
 
 
-def logit_close(got, ref, rtol=LOGIT_RTOL, scale_rtol=LOGIT_SCALE_RTOL, scale=None):
-    """Ranker-logit tolerance.  Two fp32 evaluations of the reference net with its default
-    unscaled randn cross weights (transformer_ranker.py:177-180) differ by up to 4e-4
-    relative per element (the reference's own torch output vs float64 truth, measured in
-    the build container: heads cancel terms of magnitude ~1e3) while staying within 2.5e-6
-    of the batch's logit scale; so an element passes if it is within ``rtol`` of itself
-    OR within ``scale_rtol`` of the largest |logit| of the batch (over all tasks: ``scale``)."""
+def logit_close(got, ref, cross="randn", scale=None):
+    """Ranker-logit tolerance, by conditioning of the network:
+
+    * ``cross == "scaled"`` (cross weights randn/16: logits O(1), the weights bench.py uses): the STRICT rule alone,
+      |d| <= LOGIT_STRICT_RTOL * max(1, |logit|) = 1e-5 - ten times tighter than SURVEY 8a's 1e-4; two fp32
+      evaluations of this network sit ~1e-6 apart (measured: oracle vs reference golden 0.6-0.9e-6).
+    * ``cross == "randn"`` (the reference's default unscaled randn(256,256) cross weights,
+      transformer_ranker.py:177-184: logits ~1e3 out of three 16x-amplifying layers, heads cancel): the reference's
+      OWN torch fp32 output is up to 4.4e-4 relative away from float64 truth per element while staying within 2.5e-6
+      of the batch's logit scale, so an element passes if it is within SURVEY 8a's 1e-4 * max(1,|logit|) OR within
+      LOGIT_SCALE_RTOL of the largest |logit| of the batch (``scale``, over all tasks).
+    -> (ok, max err/bound)"""
     import numpy as np
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    if scale is None:
-        scale = float(np.abs(ref).max()) if ref.size else 0.0
-    bound = np.maximum(rtol * np.maximum(1.0, np.abs(ref)), scale_rtol * scale)
+    if cross == "scaled":
+        bound = LOGIT_STRICT_RTOL * np.maximum(1.0, np.abs(ref))
+    else:
+        if scale is None:
+            scale = float(np.abs(ref).max()) if ref.size else 0.0
+        bound = np.maximum(LOGIT_RTOL * np.maximum(1.0, np.abs(ref)), LOGIT_SCALE_RTOL * scale)
     err = np.abs(got - ref)
     return bool((err <= bound).all()), float((err / bound).max()) if ref.size else 0.0

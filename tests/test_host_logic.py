@@ -77,7 +77,7 @@ def test_ranker_packing_matches_oracle(fuse):
         h2 = np.maximum(h1[:, 256 * t:256 * (t + 1)] @ _arr(pk, p.head_w2[t], (64, 256)).T
                         + _arr(pk, p.head_b2[t], (64,)), 0)
         logit = h2 @ _arr(pk, p.head_w3[t], (64,)) + _arr(pk, p.head_b3[t], (1,))[0]
-        ok, err = cases.logit_close(logit, ref[task], scale=scale)
+        ok, err = cases.logit_close(logit, ref[task], "scaled", scale=scale)
         assert ok, (task, err)
 
 
@@ -128,3 +128,17 @@ def test_split_planes_is_an_exact_three_way_bf16_split_in_kernel_layout():
     # magnitudes shrink by >= 2^-8 per plane (8 significand bits each)
     nz = w != 0
     assert np.all(np.abs(m[nz]) <= np.abs(h[nz]) * 2.0 ** -7) and np.all(np.abs(l[nz]) <= np.abs(h[nz]) * 2.0 ** -15)
+
+
+def test_index_id_codec_round_trips_types():
+    """FAISSIndex.save/load keep arbitrary ad ids as what they were (faiss_retrieval.py:208-218 pickles id_map;
+    this build's JSON form is typed) and refuse what JSON cannot carry."""
+    from amdrec import index
+    ids = [17, "ad-3", 2.5, None, np.int64(9), "17"]
+    enc = json.loads(json.dumps([index._encode_id(x) for x in ids]))
+    dec = [index._decode_id(e) for e in enc]
+    assert dec == [17, "ad-3", 2.5, None, 9, "17"] and [type(d) for d in dec] == [int, str, float, type(None), int, str]
+    assert index._decode_id("legacy") == "legacy"                 # round-1 files stored str(id)
+    for bad in ((1, 2), b"x", True, object()):
+        with pytest.raises(TypeError):
+            index._encode_id(bad)

@@ -37,7 +37,7 @@ def test_ranker_oracle_matches_reference(name, cross):
         assert list(pred) == ["ctr", "engagement", "revenue"]
         scale = cases.logit_scale({t: g[f"B{B}_{t}"] for t in pred})
         for t in pred:
-            ok, err = cases.logit_close(pred[t], g[f"B{B}_{t}"], scale=scale)
+            ok, err = cases.logit_close(pred[t], g[f"B{B}_{t}"], cross, scale=scale)
             assert ok, (name, cross, B, t, err)
 
 

@@ -220,7 +220,8 @@ def test_full_size_1m_against_oracle():
     xb = _mk(1_000_000, 256, 1234)
     user, ad, nnum = synth.demo_dims()
     xq = _mk(512, 256, 99)
-    idx = FAISSIndex(256, index_type="Flat")
+    idx = FAISSIndex(256, index_type="Flat", prefilter=_PREFILTER)       # both engines at full size
+    assert idx._mixed == (_PREFILTER == "bf16")
     idx.add(xb)
     nfix = torch.zeros(1, dtype=torch.int32, device="cuda")
     ids, D = idx.search(xq, 500)
@@ -232,4 +233,90 @@ def test_full_size_1m_against_oracle():
     # oracle on a subset
     sub = np.arange(0, 512, 22)[:24]
     rD, rI = oracle.search.flat_ip_search(xb, xq[sub], 500)
+    oracle.search.check_topk(rD, rI, D[sub], ids[sub], tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
+
+
+def test_batch_search_chunks_like_the_reference():
+    """FAISSIndex.batch_search (faiss_retrieval.py:168-194): query-chunked search + vstack == one search, for a
+    batch size that does not divide the query count, with custom ids; shapes and dtypes as search()."""
+    from amdrec.index import FAISSIndex
+    xb, xq = _mk(30_000, 128, 31), _mk(2_345, 128, 32)
+    ad_ids = (np.arange(30_000)[::-1] * 3 + 7).tolist()
+    idx = FAISSIndex(128, index_type="Flat", prefilter=_PREFILTER)
+    ora = oracle.search.FlatIndex(128)
+    idx.add(xb, ad_ids)
+    ora.add(xb, ad_ids)
+    ids, D = idx.batch_search(xq, k=50, batch_size=1000)                 # chunks of 1000, 1000, 345
+    one_ids, one_D = idx.search(xq, 50)
+    assert ids.shape == (2_345, 50) == D.shape and ids.dtype == np.int64 and D.dtype == np.float32
+    assert np.array_equal(ids, one_ids) and np.array_equal(D, one_D)      # chunking changes nothing (bit-exact)
+    sub = np.arange(0, 2_345, 97)
+    rids, rD = ora.search(xq[sub], 50)
+    _check((ids[sub], D[sub]), (rids, rD), ora, xq[sub])
+
+
+def test_mixed_worst_case_rounding():
+    """The certificate of amdrec_flat_search_mixed must hold when bf16 rounding errors of query AND row add up
+    (eps used u = 2^-9; the true unit roundoff of bf16 is 2^-8, bound 2u + u^2 = 0.00783).
+    Query and 50 'victim' rows have every component just below a bf16 midpoint (both round down: approx = 1.0,
+    exact = 1.00773).  150 'strong' rows are exactly representable with exact score 1.00738 (approx 1.0035) and a
+    medium population fixes the sampled threshold near 1.0025: with the round-1 bound the k-th re-scored value
+    (1.00738) clears tau + eps (1.0065), the certificate passes and the victims - outside the candidate list,
+    true rank 1..50 - are lost.  With the sound bound the query takes the exact fix-up scan."""
+    from amdrec import _lib
+    from amdrec.index import flat_search_mixed
+    if _PREFILTER != "bf16":
+        pytest.skip("mixed engine only")
+    rng = np.random.default_rng(77)
+    n, d, k = 20_000, 256, 100
+    base = np.float32(2.0 ** -4)
+    a = np.float32(2.0 ** -4 * (1 + 0.99 * 2.0 ** -8))                    # rounds DOWN to 2^-4 in bf16
+    bump = np.float32(2.0 ** -4 * (1 + 2.0 ** -7))                         # exactly representable in bf16
+    xb = np.full((n, d), base, dtype=np.float32)
+    kinds = np.zeros(n, dtype=np.int64)                                     # 0 weak, 1 medium, 2 strong, 3 victim
+    perm = rng.permutation(n)
+    kinds[perm[:50]] = 3
+    kinds[perm[50:200]] = 2
+    kinds[perm[200:1700]] = 1
+    for r in range(n):
+        if kinds[r] == 3:
+            xb[r, :] = a
+            continue
+        cnt = {0: rng.integers(0, 26), 1: rng.integers(77, 91), 2: 115}[int(kinds[r])]
+        xb[r, rng.choice(d, cnt, replace=False)] = bump
+    xq = np.stack([np.full(d, a, dtype=np.float32), _mk(1, d, 5)[0]])
+    X = torch.from_numpy(xb).cuda()
+    X16 = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
+    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.amdrec_bf16_rows(_lib.ptr(X), n, d, d, _lib.ptr(X16), d, _lib.ptr(mx), _lib.stream_ptr(X.device)))
+    Q = torch.from_numpy(xq).cuda()
+    D = torch.empty((2, k), dtype=torch.float32, device="cuda")
+    I = torch.empty((2, k), dtype=torch.int64, device="cuda")
+    nfix = torch.zeros(1, dtype=torch.int32, device="cuda")
+    flat_search_mixed(X, X16, mx, n, Q, k, D, I, n_fixup=nfix)
+    got_ids = I.cpu().numpy()
+    exact = xb.astype(np.float64) @ xq[0].astype(np.float64)
+    approx = X16.float().cpu().numpy().astype(np.float64) @ Q[0].to(torch.bfloat16).float().cpu().numpy().astype(np.float64)
+    victims = np.nonzero(kinds == 3)[0]
+    # the construction really is adversarial: the bf16 error of the victims exceeds the round-1 bound, not the sound one
+    rel = np.abs(approx[victims] - exact[victims]).max() / (np.linalg.norm(xq[0].astype(np.float64)) * np.linalg.norm(xb[victims[0]].astype(np.float64)))
+    assert 0.00392 + 256 * 1.2e-7 < rel < 0.00783
+    assert set(victims.tolist()) <= set(got_ids[0].tolist()), "victim rows (true rank 1..50) missing: unsound certificate"
+    rD, rI = oracle.search.flat_ip_search(xb, xq, k, dtype=np.float64)
+    oracle.search.check_topk(rD, rI, D.cpu().numpy(), got_ids, tau=cases.TOPK_TAU, score_tol=2 * cases.SCORE_ATOL)
+    assert int(nfix.item()) >= 1                                            # query 0 went through the exact fix-up
+
+
+def test_more_than_65535_queries_in_one_call():
+    """the fix-up scan used gridDim.y = nq (limit 65535); the entry points accept nq < 2^24."""
+    from amdrec.index import FAISSIndex
+    if _PREFILTER != "fp32":
+        pytest.skip("one engine is enough: both share the fix-up launch")
+    xb, xq = _mk(3_000, 32, 41), _mk(66_000, 32, 42)
+    idx = FAISSIndex(32, index_type="Flat", prefilter=_PREFILTER)
+    idx.add(xb)
+    ids, D = idx.search(xq, 5)
+    sub = np.r_[0:40, 65_500:65_560, 65_990:66_000]
+    rD, rI = oracle.search.flat_ip_search(xb, xq[sub], 5)
     oracle.search.check_topk(rD, rI, D[sub], ids[sub], tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
