@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMDREC_ABI_VERSION 3
+#define AMDREC_ABI_VERSION 4
 #define AMDREC_MAX_K 2048
 
 int amdrec_abi_version(void);
@@ -155,6 +155,27 @@ typedef struct {
     const uint16_t *w_o_x6, *w_1_x6, *w_2_x6;
 } amdrec_encoder_layer;
 
+/* Weights of the fp16x3 "row-owner" engine (csrc/rowowner.hpp; optional: stream == NULL -> engine off).  The engine
+ * runs everything after the feature projection - the encoder layers (transformer_ranker.py:136-155 with the seq-1
+ * attention :59-88), the cross layers (:199-202) and the heads (:375-378) - in ONE kernel with the activations in
+ * registers; every fp32 operand is split into two fp16 planes (after an exact power-of-two scaling) and a product is
+ * three fp16 MFMAs accumulated in fp32: fp32 in, fp32 out, error at the level of an fp32 fma chain.
+ * `stream` = all weight matrices as 1 KB MFMA fragment sets in consumption order (the packing, incl. the k permutation
+ * inside a 16-wide k-step, is defined by amdrec/weights.py pack_x3_stream and mirrored by rowowner.hpp); `sw_*` = the
+ * power-of-two scale of each packed matrix; `hn*` / `hb*` = 16 * max_j ||w_j||_2 and max_j |b_j| of the first matrix of
+ * each two-stage block (FFN per layer, heads): the kernel bounds a row's hidden activations by hn * max|x| + hb to scale them.
+ * Requires d_model == 256, d_ff % 32 == 0, head_h1 % 32 == 0, head_h2 == 64 and the pre-multiplied attention
+ * (w_v == NULL); used for passes of at least `min_rows` rows (0 = default 8193). */
+typedef struct {
+    const void* stream;
+    int64_t chunks;              /* stream length in 16 KB chunks */
+    int64_t min_rows;
+    float sw_ov[AMDREC_MAX_LAYERS], sw_1[AMDREC_MAX_LAYERS], sw_2[AMDREC_MAX_LAYERS];
+    float hn[AMDREC_MAX_LAYERS], hb[AMDREC_MAX_LAYERS];
+    float sw_cross[AMDREC_MAX_LAYERS];
+    float sw_h1, sw_h2, hn_head, hb_head;
+} amdrec_x3_weights;
+
 typedef struct {
     int32_t n_user_feat, n_ad_feat, emb_dim, n_num;
     int32_t d_model, d_ff, n_layers, n_cross, n_tasks, head_h1, head_h2;
@@ -190,6 +211,7 @@ typedef struct {
     /* Optional x6 planes (see amdrec_encoder_layer) of cross_wt[i] and head_w1. */
     const uint16_t* cross_wt_x6[AMDREC_MAX_LAYERS];
     const uint16_t* head_w1_x6;
+    amdrec_x3_weights x3;
 } amdrec_ranker_params;
 
 int amdrec_ranker_workspace(const amdrec_ranker_params* p /*host*/, int64_t rows, size_t* bytes /*host*/);
@@ -204,6 +226,15 @@ int amdrec_ranker_forward(const amdrec_ranker_params* p /*host*/, const int64_t*
                           const int64_t* ad_rowmap, int64_t rows, float* out_logits, int64_t ld_logits,
                           int* bad_index_flag, int64_t n_user_rows, int64_t n_ad_rows, void* workspace,
                           size_t workspace_bytes, void* stream);
+
+/* Test / debugging entry of the fp16x3 engine: run the first n_phases phases of the chain (phase order: per encoder
+ * layer {attention + LN1, FFN + LN2}, then the cross layers, then the heads; n_phases < 0 = all) on dense projected
+ * rows X [rows][ldx] and return the rows after the last executed phase in x_out [rows][ld_out] (may be NULL) and, when
+ * the heads ran, the logits.  workspace: >= ceil(rows / 128) * 128 * 1024 bytes.  Lets the parity tests localise an
+ * error to one phase; amdrec_ranker_forward uses the same kernel for whole passes. */
+int amdrec_ranker_x3_prefix(const amdrec_ranker_params* p /*host*/, const float* X, int64_t ldx, int64_t rows,
+                            int n_phases, float* x_out, int64_t ld_out, float* logits, int64_t ld_logits,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fills the candidate-side cache described at amdrec_ranker_params.ad_proj_cache: out[a] = w_proj_ad . emb(ad_cat[a])
  * (no bias; the user half carries it), a = 0..n_ads-1.  workspace: >= 4*d_model + 256 bytes. */

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libamdrec.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_K = 2048
 
 
@@ -48,6 +48,7 @@ _SIGNATURES = {
     "amdrec_profile_enable": [_i32],
     "amdrec_profile_report": [_vp, _i32, C.POINTER(_i32)],
     "amdrec_ranker_project_ads": [_vp, _vp, _i64, _fp, _i64, _vp, _sz, _vp],
+    "amdrec_ranker_x3_prefix": [_vp, _fp, _i64, _i64, _i32, _fp, _i64, _fp, _i64, _vp, _sz, _vp],
     "amdrec_prep_numerical": [_fp, _fp, _fp, _fp, _i64, _i32, _vp],
     "amdrec_select_topk": [_fp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _fp, _vp, _vp],
 }

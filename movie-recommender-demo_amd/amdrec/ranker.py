@@ -81,16 +81,26 @@ class TransformerRanker(nn.Module):
         # W_ov = W_o W_v pre-multiplied on the host (exact algebra at seq_len 1; set False to run the two
         # GEMMs in the reference's order)
         self.fuse_attention = True
-        # big passes (> 8192 rows) on the error-compensated bf16-MFMA GEMM ("bf16x6": fp32 inputs split exactly into
-        # three bf16 planes, six products per MAC, fp32 accumulate - fp32-level error); "fp32" = fp32 MFMA everywhere
-        self.gemm_engine = "bf16x6"
+        # engine of the big passes (> 8192 rows), all fp32 in / fp32 out with fp32-level error:
+        #  "f16x3"  (default) the row-owner kernel (csrc/rowowner.hpp): operands split into two fp16 planes, three
+        #           fp16-MFMA products per MAC, everything after the projection in ONE kernel, activations in registers
+        #  "bf16x6" the round-1 tile GEMMs on three bf16 planes, six products per MAC (also the fallback of "f16x3" for
+        #           architectures the row-owner kernel is not written for)
+        #  "fp32"   fp32 MFMA everywhere
+        self.gemm_engine = "f16x3"
+        self.x3_min_rows = self.SMALL_ROWS + 1       # tests set 1 to drive small batches through the row-owner kernel
 
-    ENGINES = ("bf16x6", "fp32")
-    SMALL_ROWS = 8192       # passes of at most this many rows always run the fp32-MFMA small shapes (csrc/layers.hip)
+    ENGINES = ("f16x3", "bf16x6", "fp32")
+    SMALL_ROWS = 8192       # passes of at most this many rows run the fp32-MFMA small shapes (csrc/layers.hip)
 
     def gemm_engine_for(self, rows: int) -> str:
         """The engine a pass of ``rows`` rows actually runs on."""
-        return self.gemm_engine if rows > self.SMALL_ROWS else "fp32"
+        eng = self.gemm_engine
+        if eng == "f16x3":
+            if weights.x3_eligible(self.state_dict(), self.fuse_attention):
+                return "f16x3" if rows >= self.x3_min_rows else "fp32"
+            eng = "bf16x6"
+        return eng if rows > self.SMALL_ROWS else "fp32"
 
     # -- packing ----------------------------------------------------------------------
     def invalidate(self):
@@ -137,13 +147,18 @@ class TransformerRanker(nn.Module):
         return c[4]
 
     def _pack(self, device):
-        if self.gemm_engine not in ("bf16x6", "fp32"):
-            raise ValueError("gemm_engine must be 'bf16x6' or 'fp32'")
-        key = (str(device), self.fuse_attention, self.gemm_engine, tuple(p._version for p in self.parameters()))
+        if self.gemm_engine not in self.ENGINES:
+            raise ValueError(f"gemm_engine must be one of {self.ENGINES}")
+        key = (str(device), self.fuse_attention, self.gemm_engine, int(self.x3_min_rows),
+               tuple(p._version for p in self.parameters()))
         if self._packed is None or self._packed[0] != key:
-            params, keep, tasks = weights.pack_ranker(self.state_dict(), self._user_names, self._ad_names,
+            sd = self.state_dict()
+            x3 = self.gemm_engine == "f16x3" and weights.x3_eligible(sd, self.fuse_attention)
+            params, keep, tasks = weights.pack_ranker(sd, self._user_names, self._ad_names,
                                                       self._n_num, device, fuse_attention=self.fuse_attention,
-                                                      x6=self.gemm_engine == "bf16x6")
+                                                      x6=self.gemm_engine == "bf16x6" or
+                                                      (self.gemm_engine == "f16x3" and not x3),
+                                                      x3=x3, x3_min_rows=self.x3_min_rows)
             self._packed = (key, params, keep, tasks)
         return self._packed[1], self._packed[3]
 

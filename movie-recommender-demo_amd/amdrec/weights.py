@@ -29,6 +29,13 @@ class EncoderLayer(C.Structure):
                [(n, _FP) for n in ("w_o_x6", "w_1_x6", "w_2_x6")]
 
 
+class X3Weights(C.Structure):
+    _fields_ = [("stream", _FP), ("chunks", C.c_int64), ("min_rows", C.c_int64),
+                ("sw_ov", C.c_float * MAX_LAYERS), ("sw_1", C.c_float * MAX_LAYERS), ("sw_2", C.c_float * MAX_LAYERS),
+                ("hn", C.c_float * MAX_LAYERS), ("hb", C.c_float * MAX_LAYERS), ("sw_cross", C.c_float * MAX_LAYERS),
+                ("sw_h1", C.c_float), ("sw_h2", C.c_float), ("hn_head", C.c_float), ("hb_head", C.c_float)]
+
+
 class RankerParams(C.Structure):
     _fields_ = [("n_user_feat", C.c_int32), ("n_ad_feat", C.c_int32), ("emb_dim", C.c_int32), ("n_num", C.c_int32),
                 ("d_model", C.c_int32), ("d_ff", C.c_int32), ("n_layers", C.c_int32), ("n_cross", C.c_int32),
@@ -43,7 +50,7 @@ class RankerParams(C.Structure):
                 ("head_w2", _FP * MAX_TASKS), ("head_b2", _FP * MAX_TASKS),
                 ("head_w3", _FP * MAX_TASKS), ("head_b3", _FP * MAX_TASKS),
                 ("ad_proj_cache", _FP), ("ld_ad_proj_cache", C.c_int64),
-                ("cross_wt_x6", _FP * MAX_LAYERS), ("head_w1_x6", _FP)]
+                ("cross_wt_x6", _FP * MAX_LAYERS), ("head_w1_x6", _FP), ("x3", X3Weights)]
 
 
 def _np64(t):
@@ -66,6 +73,100 @@ def split_planes(w32: np.ndarray) -> np.ndarray:
     planes = np.stack([(x.view(np.uint32) >> np.uint32(16)).astype(np.uint16) for x in (h, m, r2)], axis=0)
     assert np.array_equal(h + m + r2, w)                    # the split is exact
     return np.ascontiguousarray(planes.reshape(3, out_f, ld // 16, 16).transpose(1, 2, 0, 3)).view(np.int16)
+
+
+# ---- fp16x3 row-owner engine: fragment packing (mirrors csrc/rowowner.hpp) --------------------------------------------
+X3_TARGET_EXP = 12          # scaled maxima lie in [2^12, 2^13)
+# position i = 8 h + j of a k-step holds feature offset 8 (j >> 2) + 4 h + (j & 3): bits 2 and 3 of the index swap
+_X3_KSRC = np.array([(i & 3) | (((i >> 3) & 1) << 2) | (((i >> 2) & 1) << 3) for i in range(16)])
+
+
+def x3_pow2_scale(maxabs: float, target_exp: int = X3_TARGET_EXP) -> float:
+    """The power of two s with maxabs * s in [2^target_exp, 2^(target_exp+1)) (1.0 for an all-zero matrix)."""
+    if not np.isfinite(maxabs) or maxabs <= 0:
+        return 1.0
+    return float(2.0 ** (target_exp - int(np.floor(np.log2(maxabs)))))
+
+
+def x3_frags(w64: np.ndarray, scale: float) -> np.ndarray:
+    """[N][K] (N % 32 == 0, K % 16 == 0) -> uint16 [N/32][K/16][2 planes][64 lanes][8]: the fp16 planes h = RN16(w s),
+    l = RN16(w s - h) of every (32-feature tile, 16-wide k-step) as MFMA A fragments in lane order (lane = p + 32 half
+    holds k positions 8 half .. 8 half + 7 of row p), with the accumulator-as-operand k permutation applied."""
+    n, k = w64.shape
+    assert n % 32 == 0 and k % 16 == 0
+    ws = (np.asarray(w64, dtype=np.float64) * scale).astype(np.float32)        # exact: power-of-two scaling of fp32 values
+    h = ws.astype(np.float16)
+    assert np.isfinite(h).all(), "x3 weight plane overflowed fp16"
+    l = (ws - h.astype(np.float32)).astype(np.float16)
+    planes = np.stack([h, l]).view(np.uint16)                                  # [2][N][K]
+    planes = planes.reshape(2, n, k // 16, 16)[:, :, :, _X3_KSRC]              # position i <- source k offset _X3_KSRC[i]
+    planes = planes.reshape(2, n // 32, 32, k // 16, 2, 8)                     # plane, tile, p, ks, half, j
+    return np.ascontiguousarray(planes.transpose(1, 3, 0, 4, 2, 5)).reshape(n // 32, k // 16, 2, 64, 8)
+
+
+def x3_stream_gemm256(fr: np.ndarray) -> np.ndarray:
+    """fragments of a [256][256] matrix -> stream order `for ks: for tile: (h, l)` (rowowner.hpp gemm256)."""
+    return np.ascontiguousarray(fr.transpose(1, 0, 2, 3, 4)).reshape(-1, 64, 8)
+
+
+def x3_stream_ffn(f1: np.ndarray, f2: np.ndarray) -> np.ndarray:
+    """f1 = fragments of W_1 [d_ff][256], f2 = of W_2 [256][d_ff] -> rowowner.hpp ffn_step order: step t = 0 .. T:
+    per micro-step u = 0..15: stage 1 (tile t, ks u) if t < T, then stage 2 (tile u & 7, ks 2 (t - 1) + (u >> 3)) if t >= 1."""
+    T = f1.shape[0]
+    out = []
+    for t in range(T + 1):
+        for u in range(16):
+            if t < T:
+                out += [f1[t, u, 0], f1[t, u, 1]]
+            if t >= 1:
+                i, ks = u & 7, 2 * (t - 1) + (u >> 3)
+                out += [f2[i, ks, 0], f2[i, ks, 1]]
+    return np.stack(out)
+
+
+def x3_stream_heads(f1: np.ndarray, f2s: List[np.ndarray], tiles_per_task: int) -> np.ndarray:
+    """f1 = fragments of the stacked head layer 1 [n_tasks * h1][256]; f2s[t] = of head t's layer 2 [64][h1] ->
+    rowowner.hpp phase_heads order: per task, per hidden tile: 16 x (h, l) of stage 1, then for s in 0, 1: for i in 0, 1: (h, l)."""
+    out = []
+    for task, f2 in enumerate(f2s):
+        for t in range(tiles_per_task):
+            for u in range(16):
+                out += [f1[task * tiles_per_task + t, u, 0], f1[task * tiles_per_task + t, u, 1]]
+            for sp in range(2):
+                for i in range(2):
+                    out += [f2[i, 2 * t + sp, 0], f2[i, 2 * t + sp, 1]]
+    return np.stack(out)
+
+
+def pack_x3_stream(mats: Dict) -> Dict:
+    """mats: float64 matrices of the chain {"ov": [L x [256][256]], "w1": [L x [d_ff][256]], "b1": [L x [d_ff]], "w2":
+    [L x [256][d_ff]], "cross": [C x [256][256] (already [out][in])], "h1": [T*h1][256], "hb1": [T*h1], "h2": [T x
+    [64][h1]]} -> {"stream": uint16 [n_frag][64][8], "chunks", scales and hidden bounds} for amdrec_x3_weights."""
+    parts = []
+    sc = {"sw_ov": [], "sw_1": [], "sw_2": [], "hn": [], "hb": [], "sw_cross": []}
+    for l in range(len(mats["ov"])):
+        s_ov = x3_pow2_scale(np.abs(mats["ov"][l]).max())
+        parts.append(x3_stream_gemm256(x3_frags(mats["ov"][l], s_ov)))
+        s1, s2 = x3_pow2_scale(np.abs(mats["w1"][l]).max()), x3_pow2_scale(np.abs(mats["w2"][l]).max())
+        parts.append(x3_stream_ffn(x3_frags(mats["w1"][l], s1), x3_frags(mats["w2"][l], s2)))
+        sc["sw_ov"].append(s_ov); sc["sw_1"].append(s1); sc["sw_2"].append(s2)
+        # |relu(w_j . x + b_j)| <= ||w_j||_2 ||x||_2 + |b_j| <= (16 max_j ||w_j||_2) max|x| + max_j |b_j|
+        sc["hn"].append(float(16.0 * np.linalg.norm(mats["w1"][l], axis=1).max() * (1 + 1e-6)))
+        sc["hb"].append(float(np.abs(mats["b1"][l]).max()))
+    for w in mats["cross"]:
+        s = x3_pow2_scale(np.abs(w).max())
+        parts.append(x3_stream_gemm256(x3_frags(w, s)))
+        sc["sw_cross"].append(s)
+    sh1 = x3_pow2_scale(np.abs(mats["h1"]).max())
+    sh2 = x3_pow2_scale(max(np.abs(w).max() for w in mats["h2"]))
+    n_tasks = len(mats["h2"])
+    tiles = mats["h1"].shape[0] // n_tasks // 32
+    parts.append(x3_stream_heads(x3_frags(mats["h1"], sh1), [x3_frags(w, sh2) for w in mats["h2"]], tiles))
+    stream = np.concatenate(parts)
+    assert stream.shape[0] % 16 == 0
+    return {"stream": stream, "chunks": stream.shape[0] // 16, "sw_h1": sh1, "sw_h2": sh2,
+            "hn_head": float(16.0 * np.linalg.norm(mats["h1"], axis=1).max() * (1 + 1e-6)),
+            "hb_head": float(np.abs(mats["hb1"]).max()), **sc}
 
 
 def _pad_k(w64, mult=32):
@@ -142,8 +243,31 @@ def pack_tower(sd: Dict, prefix: str, feature_names: List[str], n_num: int, devi
     return p, pk
 
 
+def x3_eligible(sd: Dict, fuse_attention: bool) -> bool:
+    """The architecture the row-owner engine is written for (the reference's: d_model 256, heads 256 -> 64 -> 1)."""
+    if not fuse_attention or "feature_projection.weight" not in sd:
+        return False
+    dm = int(sd["feature_projection.weight"].shape[0])
+    if dm != 256:
+        return False
+    l = 0
+    while f"transformer_layers.{l}.norm1.weight" in sd:
+        if int(sd[f"transformer_layers.{l}.feed_forward.fc1.weight"].shape[0]) % 32:
+            return False
+        l += 1
+    c = 0
+    while f"feature_interaction.cross_weights.{c}" in sd:
+        c += 1
+    tasks = [t for t in TASKS if f"prediction_heads.{t}.0.weight" in sd]
+    if not tasks or 2 * l + c + 1 > 20 or len(tasks) > MAX_TASKS:
+        return False
+    h1 = int(sd[f"prediction_heads.{tasks[0]}.0.weight"].shape[0])
+    h2 = int(sd[f"prediction_heads.{tasks[0]}.3.weight"].shape[0])
+    return h1 % 32 == 0 and h2 == 64
+
+
 def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int, device, ln_eps=1e-5,
-                fuse_attention: bool = True, x6: bool = True):
+                fuse_attention: bool = True, x6: bool = True, x3: bool = False, x3_min_rows: int = 0):
     """state_dict-like of the reference TransformerRanker -> (RankerParams, Packed, task names).
     ``fuse_attention``: pre-multiply W_ov = W_o W_v, b_ov = W_o b_v + b_o in float64 (the seq-len-1
     attention is exactly W_o(W_v x + b_v) + b_o, transformer_ranker.py:59-88 with :358), so each
@@ -233,4 +357,30 @@ def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int
         p.head_w3[i] = pk.ptr(_np64(sd[f"prediction_heads.{t}.6.weight"]).reshape(-1).astype(np.float32))
         p.head_b3[i] = pk.ptr(_np64(sd[f"prediction_heads.{t}.6.bias"]).reshape(-1).astype(np.float32))
     p.ln_eps = ln_eps
+    if x3 and x3_eligible(sd, fuse_attention):
+        # the SAME fp32-rounded matrices the other engines multiply with, split into fp16 planes in stream order
+        f32 = lambda a: np.asarray(a, dtype=np.float64).astype(np.float32).astype(np.float64)   # noqa: E731
+        mats = {"ov": [], "w1": [], "b1": [], "w2": [], "cross": [], "h2": []}
+        for li in range(p.n_layers):
+            pre = f"transformer_layers.{li}"
+            wv, wo = _np64(sd[f"{pre}.self_attention.W_v.weight"]), _np64(sd[f"{pre}.self_attention.W_o.weight"])
+            mats["ov"].append(f32(wo @ wv))
+            mats["w1"].append(f32(_np64(sd[f"{pre}.feed_forward.fc1.weight"])))
+            mats["b1"].append(f32(_np64(sd[f"{pre}.feed_forward.fc1.bias"])))
+            mats["w2"].append(f32(_np64(sd[f"{pre}.feed_forward.fc2.weight"])))
+        for ci in range(p.n_cross):
+            mats["cross"].append(f32(_np64(sd[f"feature_interaction.cross_weights.{ci}"]).T))
+        mats["h1"], mats["hb1"] = f32(w1), f32(b1)
+        for t in tasks:
+            mats["h2"].append(f32(_np64(sd[f"prediction_heads.{t}.3.weight"])))
+        x = pack_x3_stream(mats)
+        p.x3.stream = pk.ptr(x["stream"].view(np.int16))
+        p.x3.chunks = x["chunks"]
+        p.x3.min_rows = int(x3_min_rows)
+        for li in range(p.n_layers):
+            p.x3.sw_ov[li], p.x3.sw_1[li], p.x3.sw_2[li] = x["sw_ov"][li], x["sw_1"][li], x["sw_2"][li]
+            p.x3.hn[li], p.x3.hb[li] = x["hn"][li], x["hb"][li]
+        for ci in range(p.n_cross):
+            p.x3.sw_cross[ci] = x["sw_cross"][ci]
+        p.x3.sw_h1, p.x3.sw_h2, p.x3.hn_head, p.x3.hb_head = x["sw_h1"], x["sw_h2"], x["hn_head"], x["hb_head"]
     return p, pk, tasks

@@ -594,6 +594,12 @@ extern "C" int amdrec_tower_forward(const amdrec_tower_params* p, const int64_t*
 }
 
 // ============================== ranker ==============================================
+namespace amdrec {   // ranker_x3.hip: the fp16x3 row-owner engine (everything after the feature projection in one kernel)
+bool ranker_x3_wanted(const amdrec_ranker_params* p, long long rows);
+int ranker_x3_run(const amdrec_ranker_params* p, const float* X, long long ldx, const float* U, const long long* rowmap,
+                  long long row_base, int rowdiv, long long n_cache, long long rows, float* scratch, float* logits,
+                  long long ld_logits, hipStream_t st);
+}
 static int ranker_check(const amdrec_ranker_params* p) {
     REQUIRE(p != nullptr, "params is null");
     REQUIRE(p->n_user_feat >= 0 && p->n_ad_feat >= 0 && p->n_user_feat + p->n_ad_feat >= 1 &&
@@ -752,6 +758,16 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         g.rows1 = n_ad_rows > 0 ? n_ad_rows : 1;
         g.rows = m; g.F = F; g.F0 = F0; g.E = p->emb_dim; g.eshift = ilog2(p->emb_dim);
         g.n_num = p->n_num; g.cat0_rowdiv = (int)user_rowdiv;
+        // fp16x3 row-owner engine: the rest of the chain is one kernel; with the candidate-side cache it also does the
+        // gather (x0 = cache row + user half).  Its x0 scratch is the X0 region (+ up to 127 padding rows, which run into
+        // the H region behind it: unused on this path and at least 4x as large).
+        const bool use_x3 = ranker_x3_wanted(p, m);
+        if (use_x3 && hoist && p->ad_proj_cache) {
+            int rc3 = ranker_x3_run(p, nullptr, 0, (const float*)U, (const long long*)ad_rowmap, r0, (int)user_rowdiv,
+                                    (long long)(n_ad_rows > 0 ? n_ad_rows : 1), m, X0, out_logits + r0, (long long)ld_logits, st);
+            if (rc3) return rc3;
+            continue;
+        }
         if (hoist && p->ad_proj_cache) {
             hipLaunchKernelGGL(proj_gather_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, p->ad_proj_cache,
                                (long long)p->ld_ad_proj_cache, (long long)(n_ad_rows > 0 ? n_ad_rows : 1),
@@ -766,6 +782,12 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         } else {
             HIP_TRY(linear_wide<EpiLinearT>(p->w_proj, nullptr, p->ldw_proj, dm, g, m, st, F * p->emb_dim + p->n_num,
                                             p->b_proj, X, (long long)dm, m, dm, 0));
+        }
+        if (use_x3) {
+            int rc3 = ranker_x3_run(p, (const float*)X, (long long)dm, nullptr, nullptr, 0, 1, 0, m, X0, out_logits + r0,
+                                    (long long)ld_logits, st);
+            if (rc3) return rc3;
+            continue;
         }
         // ---- encoder layers ----
         for (int l = 0; l < p->n_layers; ++l) {

@@ -1,0 +1,180 @@
+// The fp16x3 row-owner engine of amdrec_ranker_forward (kernel machinery and numerics: rowowner.hpp).
+//   ranker_x3_kernel : input rows (dense X or cached-projection gather) -> all phases of the chain -> logits
+//   amdrec_ranker_x3_prefix : debugging / test entry: run the first n phases on a dense X and return the rows
+#include "rowowner.hpp"
+#include "../../include/amdrec.h"
+
+namespace amdrec {
+namespace x3 {
+
+__global__ __launch_bounds__(256, 1) void ranker_x3_kernel(Program G, Input in, long long rows, float* scratch,
+                                                           float* x_out, long long ld_xout, float* logits,
+                                                           long long ld_logits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, q = lane & 31;
+    const long long row = (long long)blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE + q;
+    const bool row_ok = row < rows;
+    const long long rowc = row_ok ? row : rows - 1;                 // clamped: branch-free loads, stores are guarded
+
+    Ring ring;
+    ring.start(G.stream, G.total_chunks, (lds_byte*)smem, wave, lane);
+
+    f32x16 x[8];
+    if (in.X != nullptr) {
+        load_rows(x, in.X + rowc * in.ldx, h);
+    } else {
+        const long long gr = in.row_base + rowc;
+        long long a = in.rowmap ? in.rowmap[gr] : gr;
+        a = a < 0 ? 0 : (a >= in.n_cache ? in.n_cache - 1 : a);     // clamped like the gather loader (reported separately)
+        load_rows(x, in.cache + a * in.ldc, h);
+        add_rows(x, in.U + (gr / in.rowdiv) * 256, h);              // cache row + the user's half (same order as proj_gather)
+    }
+    float* x0_row = scratch + row * 256;                            // this lane's own row (scratch is padded to whole workgroups)
+    bool x0_saved = false;
+    for (int p = 0; p < G.n_phases; ++p) {
+        const Phase& P = G.ph[p];
+        const int type = __builtin_amdgcn_readfirstlane(P.type);
+        if (type == PH_ATTN_LN) {
+            phase_attn_ln(ring, P, x, h);
+        } else if (type == PH_FFN_LN) {
+            phase_ffn_ln(ring, P, x, h);
+        } else if (type == PH_CROSS) {
+            if (!x0_saved) {                                        // x0 = the encoder output, kept for all cross layers
+                store_rows(x, x0_row, h);
+                x0_saved = true;
+            }
+            phase_cross(ring, P, x, x0_row, h);
+        } else {
+            phase_heads(ring, G, P, x, logits, ld_logits, row, row_ok, h);
+        }
+    }
+    if (x_out != nullptr && row_ok) store_rows(x, x_out + row * ld_xout, h);
+    ring.drain();                                                   // no LDS-DMA may land after the workgroup's LDS is released
+}
+
+}  // namespace x3
+}  // namespace amdrec
+
+using namespace amdrec;
+
+// eligibility of the engine for these parameters (the reference architecture: d_model 256, 64-wide head layer 2)
+static bool x3_eligible(const amdrec_ranker_params* p) {
+    if (p->x3.stream == nullptr || p->x3.chunks <= 0) return false;
+    if (p->d_model != 256 || p->d_ff % 32 != 0 || p->head_h1 % 32 != 0 || p->head_h2 != 64) return false;
+    if (2 * p->n_layers + p->n_cross + 1 > x3::MAX_PHASES || p->n_tasks > 4) return false;
+    for (int l = 0; l < p->n_layers; ++l)
+        if (p->layers[l].w_v != nullptr) return false;              // needs the pre-multiplied W_ov form
+    return true;
+}
+
+// n_phases < 0: the whole chain
+static int x3_build(const amdrec_ranker_params* p, int n_phases, x3::Program& G) {
+    memset(&G, 0, sizeof(G));
+    int n = 0;
+    for (int l = 0; l < p->n_layers; ++l) {
+        const amdrec_encoder_layer& L = p->layers[l];
+        x3::Phase& A = G.ph[n++];
+        A.type = x3::PH_ATTN_LN; A.b1 = L.b_o; A.gamma = L.ln1_g; A.beta = L.ln1_b; A.sw1 = p->x3.sw_ov[l];
+        A.sw2 = 1.f; A.ln_eps = p->ln_eps;
+        x3::Phase& F = G.ph[n++];
+        F.type = x3::PH_FFN_LN; F.n_steps = p->d_ff / 32; F.b1 = L.b_1; F.b2 = L.b_2; F.gamma = L.ln2_g; F.beta = L.ln2_b;
+        F.sw1 = p->x3.sw_1[l]; F.sw2 = p->x3.sw_2[l]; F.hn = p->x3.hn[l]; F.hb = p->x3.hb[l]; F.ln_eps = p->ln_eps;
+    }
+    for (int c = 0; c < p->n_cross; ++c) {
+        x3::Phase& C = G.ph[n++];
+        C.type = x3::PH_CROSS; C.b1 = p->cross_b[c]; C.sw1 = p->x3.sw_cross[c]; C.sw2 = 1.f;
+    }
+    x3::Phase& H = G.ph[n++];
+    H.type = x3::PH_HEADS; H.n_steps = p->head_h1 / 32; H.n_tasks = p->n_tasks; H.b1 = p->head_b1;
+    H.sw1 = p->x3.sw_h1; H.sw2 = p->x3.sw_h2; H.hn = p->x3.hn_head; H.hb = p->x3.hb_head;
+    for (int t = 0; t < p->n_tasks; ++t) { G.hb2[t] = p->head_b2[t]; G.hw3[t] = p->head_w3[t]; G.hb3[t] = p->head_b3[t]; }
+    // chunks consumed by a prefix of the chain (the ring only needs to know where the stream ends)
+    const long long per_layer = 16 + 4ll * (p->d_ff / 32);          // W_ov: 16 chunks; FFN: 64 fragment sets per hidden tile
+    const long long heads = (long long)p->n_tasks * (p->head_h1 / 32) * 40 / 16;
+    REQUIRE((long long)p->n_tasks * (p->head_h1 / 32) * 40 % 16 == 0, "x3: head stream is not a whole number of chunks");
+    const long long total = p->n_layers * per_layer + 16ll * p->n_cross + heads;
+    REQUIRE(total == p->x3.chunks, "x3: stream length %lld chunks does not match the architecture (%lld)",
+            (long long)p->x3.chunks, total);
+    G.n_phases = n_phases < 0 || n_phases > n ? n : n_phases;
+    G.total_chunks = (int)total;
+    G.stream = reinterpret_cast<const unsigned char*>(p->x3.stream);
+    return AMDREC_OK;
+}
+
+static size_t x3_scratch_bytes(long long rows) {
+    return (size_t)((rows + x3::ROWS_PER_WG - 1) / x3::ROWS_PER_WG) * x3::ROWS_PER_WG * 256 * 4;
+}
+
+static int x3_launch(const x3::Program& G, const x3::Input& in, long long rows, float* scratch, float* x_out,
+                     long long ld_xout, float* logits, long long ld_logits, hipStream_t st) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(x3::ranker_x3_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES));
+        attr_done.mark();
+    }
+    const unsigned grid = (unsigned)((rows + x3::ROWS_PER_WG - 1) / x3::ROWS_PER_WG);
+    {
+        // algorithmic FLOPs: 2 * rows * sum over the phases' weight elements (bench.py prices them against bf16 MFMA / 3)
+        double w = 0;
+        for (int i = 0; i < G.n_phases; ++i) {
+            const x3::Phase& P = G.ph[i];
+            if (P.type == x3::PH_ATTN_LN || P.type == x3::PH_CROSS) w += 256.0 * 256.0;
+            else if (P.type == x3::PH_FFN_LN) w += 2.0 * 256.0 * 32.0 * P.n_steps;
+            else w += (double)P.n_tasks * (256.0 * 32.0 * P.n_steps + 64.0 * 32.0 * P.n_steps + 64.0);
+        }
+        ProfScope prof("ranker_rowowner_128_x3", 2.0 * (double)rows * w, (double)rows * (1024.0 + 12.0), st);
+        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES, st, G, in, rows, scratch, x_out,
+                           ld_xout, logits, ld_logits);
+    }
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
+
+// used by amdrec_ranker_forward (layers.hip)
+namespace amdrec {
+bool ranker_x3_wanted(const amdrec_ranker_params* p, long long rows) {
+    const long long min_rows = p->x3.min_rows > 0 ? p->x3.min_rows : 8193;
+    return rows >= min_rows && x3_eligible(p);
+}
+size_t ranker_x3_scratch_bytes(long long rows) { return x3_scratch_bytes(rows); }
+int ranker_x3_run(const amdrec_ranker_params* p, const float* X, long long ldx, const float* U, const long long* rowmap,
+                  long long row_base, int rowdiv, long long n_cache, long long rows, float* scratch, float* logits,
+                  long long ld_logits, hipStream_t st) {
+    x3::Program G;
+    int rc = x3_build(p, -1, G);
+    if (rc) return rc;
+    x3::Input in{};
+    if (X != nullptr) {
+        in.X = X; in.ldx = ldx;
+    } else {
+        in.cache = p->ad_proj_cache; in.ldc = p->ld_ad_proj_cache; in.n_cache = n_cache; in.rowmap = rowmap; in.U = U;
+        in.row_base = row_base; in.rowdiv = rowdiv;
+    }
+    return x3_launch(G, in, rows, scratch, nullptr, 0, logits, ld_logits, st);
+}
+}  // namespace amdrec
+
+extern "C" int amdrec_ranker_x3_prefix(const amdrec_ranker_params* p, const float* X, int64_t ldx, int64_t rows,
+                                       int n_phases, float* x_out, int64_t ld_out, float* logits, int64_t ld_logits,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    REQUIRE(p != nullptr && X != nullptr, "null pointer");
+    REQUIRE(x3_eligible(p), "these parameters are not eligible for the fp16x3 engine (or carry no x3 stream)");
+    if (rows <= 0) return AMDREC_OK;
+    REQUIRE(ldx >= 256 && ldx % 4 == 0 && ((uintptr_t)X % 16) == 0, "bad X layout");
+    REQUIRE(x_out == nullptr || (ld_out >= 256 && ld_out % 4 == 0 && ((uintptr_t)x_out % 16) == 0), "bad x_out layout");
+    x3::Program G;
+    int rc = x3_build(p, n_phases, G);
+    if (rc) return rc;
+    const bool heads = G.n_phases == 2 * p->n_layers + p->n_cross + 1;
+    REQUIRE(!heads || (logits != nullptr && ld_logits >= rows), "the full chain needs a logits buffer");
+    const size_t need = x3_scratch_bytes(rows);
+    if (!workspace || workspace_bytes < need)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    x3::Input in{};
+    in.X = X; in.ldx = ldx;
+    return x3_launch(G, in, rows, reinterpret_cast<float*>(workspace), x_out, ld_out, logits, ld_logits,
+                     reinterpret_cast<hipStream_t>(stream));
+}

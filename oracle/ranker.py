@@ -116,6 +116,37 @@ def trunk(sd, user_cat, ad_cat, numerical, full_attention=False):
     return cross(sd, x)
 
 
+def chain_states(sd, x, dtype=np.float64):
+    """Rows ``x`` [B, d_model] (the feature projection's output incl. pos[0]) -> the list of row states after each phase
+    of the chain in the order the row-owner kernel runs them: per encoder layer [LN1(x + attn), LN2(x + ffn)], then
+    each cross layer, and finally the logits dict.  Same arithmetic as ``forward`` (tests localise an error to a phase)."""
+    _DT[0] = dtype
+    try:
+        x = np.asarray(x).astype(dtype)
+        states = []
+        l = 0
+        while f"transformer_layers.{l}.norm1.weight" in sd:
+            p = f"transformer_layers.{l}"
+            a = mha_seq1(sd, p + ".self_attention", x)
+            x = layer_norm(x + a, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"])
+            states.append(x)
+            h = np.maximum(_lin(sd, p + ".feed_forward.fc1", x), dtype(0))
+            x = layer_norm(x + _lin(sd, p + ".feed_forward.fc2", h), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"])
+            states.append(x)
+            l += 1
+        x0, xl = x, x
+        i = 0
+        while f"feature_interaction.cross_weights.{i}" in sd:
+            w = sd[f"feature_interaction.cross_weights.{i}"].astype(dtype)
+            xl = (x0 * (xl @ w + sd[f"feature_interaction.cross_biases.{i}"].astype(dtype)) + xl).astype(dtype)
+            states.append(xl)
+            i += 1
+        states.append({t: head(sd, t, xl) for t in TASKS})
+        return states
+    finally:
+        _DT[0] = np.float32
+
+
 def forward(sd, user_cat, ad_cat, numerical, full_attention=False, dtype=np.float32):
     """-> dict of logits, keys in the reference's order (transformer_ranker.py:375-378).
     ``dtype=np.float64`` evaluates the same network in double precision: the "truth" against which the fp32-level

@@ -1,0 +1,114 @@
+"""The fp16x3 row-owner engine (csrc/rowowner.hpp) phase by phase: amdrec_ranker_x3_prefix runs the first n phases of
+the chain on projected rows and returns the row state, which is compared with a float64 evaluation of the same prefix
+(oracle.ranker.chain_states).  An error is thereby localised to one phase (attention + LN1, FFN + LN2, a cross layer,
+the heads) instead of showing up as a wrong logit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from amdrec import synth
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name, cross):
+    from amdrec.ranker import TransformerRanker
+    user, ad, nnum, sd, _ = cases.ranker_case(name, cross)
+    m = TransformerRanker(dict(user), dict(ad), nnum)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return m.cuda().eval(), sd, (user, ad, nnum)
+
+
+def _projected_rows(sd, dims, rows, seed):
+    user, ad, nnum = dims
+    uc, un = synth.user_batch(user, nnum, rows, seed=seed)
+    ac = synth.ad_features(ad, rows, seed=seed + 1)
+    feats = oracle.ranker.embed_features(sd, uc, ac, un)
+    return (feats @ sd["feature_projection.weight"].T + sd["feature_projection.bias"]
+            + sd["positional_encoding"][0, 0]).astype(np.float32)
+
+
+def _prefix(m, X, n_phases):
+    from amdrec import _lib
+    lib = _lib.load()
+    dev = X.device
+    params, tasks = m._pack(dev)
+    rows = X.shape[0]
+    x_out = torch.full((rows, 256), float("nan"), dtype=torch.float32, device=dev)
+    logits = torch.full((len(tasks), rows), float("nan"), dtype=torch.float32, device=dev)
+    ws = torch.empty(((rows + 127) // 128) * 128 * 1024, dtype=torch.uint8, device=dev)
+    _lib.check(lib.amdrec_ranker_x3_prefix(C.byref(params), _lib.ptr(X), X.stride(0), rows, n_phases, _lib.ptr(x_out),
+                                           x_out.stride(0), _lib.ptr(logits), logits.stride(0), _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    return x_out.cpu().numpy(), logits.cpu().numpy()
+
+
+@pytest.mark.parametrize("cross", ["scaled", "randn"])
+def test_every_prefix_of_the_chain_matches_float64(cross, accuracy):
+    m, sd, dims = _model("demo", cross)
+    assert m.gemm_engine == "f16x3" and m.gemm_engine_for(10_000) == "f16x3"
+    rows = 128 * 3 + 45                                  # three full workgroups and a ragged one
+    X = _projected_rows(sd, dims, rows, seed=41)
+    truth = oracle.ranker.chain_states(sd, X, dtype=np.float64)
+    f32 = oracle.ranker.chain_states(sd, X, dtype=np.float32)
+    Xd = torch.from_numpy(X).cuda()
+    n_total = len(truth)
+    names = [f"L{l}.{k}" for l in range(3) for k in ("attn_ln1", "ffn_ln2")] + [f"cross{c}" for c in range(3)] + ["heads"]
+    assert n_total == len(names) == 10
+    for n in range(1, n_total + 1):
+        x, logits = _prefix(m, Xd, n)
+        if n < n_total:
+            ref = truth[n - 1]
+            scale = np.abs(ref).max(axis=1, keepdims=True)            # per-row magnitude
+            err = float((np.abs(x - ref) / scale).max())
+            err32 = float((np.abs(f32[n - 1] - ref) / scale).max())   # the numpy fp32 evaluation of the same prefix
+            accuracy(f"x3_prefix/demo_{cross}/{names[n - 1]}", "f16x3", err / max(err32, 1e-30),
+                     rel_err_vs_float64=err, numpy_fp32_rel_err_vs_float64=err32)
+            assert np.isfinite(x).all(), names[n - 1]
+            assert err <= 4 * err32 + 2e-6, (names[n - 1], err, err32)
+        else:
+            scale = cases.logit_scale(truth[-1])
+            for ti, t in enumerate(oracle.ranker.TASKS):
+                ok, e = cases.logit_close(logits[ti], truth[-1][t], cross, scale=scale)
+                accuracy(f"x3_prefix/demo_{cross}/heads/{t}", "f16x3", e)
+                assert ok, (t, e)
+
+
+def test_x3_whole_forward_small_batches_match_reference_golden(accuracy):
+    """x3_min_rows = 1 drives the reference's golden batches (1, 7, 64 rows) through the row-owner kernel."""
+    from tests.conftest import load_golden
+    for cross in ("scaled", "randn"):
+        m, sd, _ = _model("demo", cross)
+        m.x3_min_rows = 1
+        g = load_golden(f"ranker_demo_{cross}.npz")
+        for B in (1, 7, 64):
+            assert m.gemm_engine_for(B) == "f16x3"
+            cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
+            pred = m(cu(g[f"B{B}_user_cat"]), cu(g[f"B{B}_ad_cat"]), cu(g[f"B{B}_user_num"]))
+            scale = cases.logit_scale({t: g[f"B{B}_{t}"] for t in pred})
+            for t in pred:
+                ok, err = cases.logit_close(pred[t].cpu().numpy(), g[f"B{B}_{t}"], cross, scale=scale)
+                accuracy(f"golden/demo_{cross}/B{B}/{t}", "f16x3", err)
+                assert ok, (cross, B, t, err)
+
+
+def test_x3_extreme_rows_do_not_overflow():
+    """Rows spanning 60 binades (all-zero, 1e-30, 1e+6 scales) stay finite: the per-row power-of-two scaling keeps every
+    fp16 plane in range whatever the row's magnitude."""
+    m, sd, dims = _model("demo", "scaled")
+    X = _projected_rows(sd, dims, 256, seed=43)
+    X[0] = 0.0
+    X[1] *= 1e-30
+    X[2] *= 1e6
+    X[3, :] = 0.0
+    X[3, 17] = 5e4
+    truth = oracle.ranker.chain_states(sd, X, dtype=np.float64)
+    x, _ = _prefix(m, torch.from_numpy(X).cuda(), 2)
+    assert np.isfinite(x).all()
+    ref = truth[1]
+    assert (np.abs(x - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= 2e-5

@@ -1,0 +1,165 @@
+"""CPU test of the fp16x3 weight-stream packer (amdrec/weights.py) against a numpy emulation of how the row-owner
+kernel consumes it (csrc/rowowner.hpp): fragment sets are read strictly in stream order by loops that mirror
+gemm256 / ffn_step / phase_heads, the B operand is built from the accumulator layout exactly as split8 does, and an
+MFMA is emulated by its lane semantics  D[p][q] += sum_{half, j} A[lane p + 32 half][j] * B[lane q + 32 half][j].
+If the k permutation or the stream order of the packer and the kernel disagree, the emulated chain is wrong."""
+import numpy as np
+
+import oracle
+from amdrec import synth, weights
+from tests import cases
+
+F = np.float64
+
+
+def _acc_layout_feature(i, r, h):
+    return 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+class Stream:
+    def __init__(self, frags):
+        self.f = frags.view(np.float16).astype(F)      # [n][64][8]
+        self.pos = 0
+
+    def read(self, n):
+        out = self.f[self.pos:self.pos + n]
+        self.pos += n
+        return out
+
+
+def _b_frags(x):
+    """rows x [q][256] (real values, already 'scaled') -> B fragments [16 ks][64 lanes][8] from the accumulator layout:
+    lane (q, h) element j of k-step 2 i + s = register 8 s + j of tile i."""
+    q_n = x.shape[0]
+    assert q_n == 32
+    out = np.zeros((16, 64, 8), F)
+    for i in range(8):
+        for sp in range(2):
+            for h in range(2):
+                for j in range(8):
+                    out[2 * i + sp, 32 * h:32 * h + 32, j] = x[:, _acc_layout_feature(i, 8 * sp + j, h)]
+    return out
+
+
+def _mfma(a, b):
+    """a, b: [64][8] fragments -> D [32 p][32 q]"""
+    d = np.zeros((32, 32), F)
+    for h in range(2):
+        d += a[32 * h:32 * h + 32] @ b[32 * h:32 * h + 32].T
+    return d
+
+
+def _tile_to_rows(acc_tiles):
+    """list of D tiles [32 p][32 q] (tile i = features 32 i ..) -> rows [q][32 * n]"""
+    return np.concatenate([t.T for t in acc_tiles], axis=1)
+
+
+def _gemm256(st, xb):
+    acc = [np.zeros((32, 32), F) for _ in range(8)]
+    for ks in range(16):
+        for ip in range(4):
+            cur = st.read(4)
+            for k, i in enumerate((2 * ip, 2 * ip + 1)):
+                acc[i] += _mfma(cur[2 * k] + cur[2 * k + 1], xb[ks])      # planes recombined: (ah + al) . b
+    return _tile_to_rows(acc)
+
+
+def _ffn(st, xb, T, b1, relu_scale=1.0):
+    acc2 = [np.zeros((32, 32), F) for _ in range(8)]
+    hb = None
+    for t in range(T + 1):
+        acc1 = np.zeros((32, 32), F)
+        for u in range(16):
+            if t < T:
+                a = st.read(2)
+                acc1 += _mfma(a[0] + a[1], xb[u])
+            if t >= 1:
+                a = st.read(2)
+                acc2[u & 7] += _mfma(a[0] + a[1], hb[u >> 3])
+        if t < T:
+            hrows = np.maximum(acc1.T + b1[32 * t:32 * t + 32][None, :], 0) * relu_scale     # [q][32 hidden], natural order
+            # hidden tile in accumulator layout -> its two B fragments (registers 0..7, 8..15)
+            hb = np.zeros((2, 64, 8), F)
+            for sp in range(2):
+                for h in range(2):
+                    for j in range(8):
+                        hb[sp, 32 * h:32 * h + 32, j] = hrows[:, _acc_layout_feature(0, 8 * sp + j, h)]
+    return _tile_to_rows(acc2)
+
+
+def test_stream_order_and_k_permutation_match_the_kernel_loops():
+    user, ad, nnum, sd, _ = cases.ranker_case("demo", "scaled")
+    p, pk, tasks = weights.pack_ranker(sd, list(user), list(ad), nnum, "cpu", x3=True)
+    assert p.x3.stream and p.x3.chunks == 3 * (16 + 128) + 3 * 16 + 60
+    stream = None
+    for t in pk._keep:
+        if t.data_ptr() == p.x3.stream:
+            stream = t.numpy().view(np.uint16).reshape(-1, 64, 8)
+    assert stream is not None and stream.shape[0] == p.x3.chunks * 16
+    st = Stream(stream)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((32, 256))
+    f64 = lambda k: np.asarray(sd[k], dtype=F)     # noqa: E731
+    for l in range(3):
+        pre = f"transformer_layers.{l}"
+        wov = (f64(pre + ".self_attention.W_o.weight") @ f64(pre + ".self_attention.W_v.weight")).astype(np.float32).astype(F)
+        got = _gemm256(st, _b_frags(x)) / p.x3.sw_ov[l]
+        assert np.abs(got - x @ wov.T).max() <= 1e-5 * np.abs(x @ wov.T).max(), ("ov", l)
+        w1, b1, w2 = f64(pre + ".feed_forward.fc1.weight"), f64(pre + ".feed_forward.fc1.bias"), f64(pre + ".feed_forward.fc2.weight")
+        got = _ffn(st, _b_frags(x), 32, b1 * p.x3.sw_1[l]) / (p.x3.sw_1[l] * p.x3.sw_2[l])
+        ref = np.maximum(x @ w1.T + b1, 0) @ w2.T
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), ("ffn", l)
+        # the hidden bound really bounds the hidden activations of these rows
+        hid = np.maximum(x @ w1.T + b1, 0)
+        assert (hid.max(axis=1) <= p.x3.hn[l] * np.abs(x).max(axis=1) + p.x3.hb[l]).all()
+    for c in range(3):
+        wc = f64(f"feature_interaction.cross_weights.{c}")
+        got = _gemm256(st, _b_frags(x)) / p.x3.sw_cross[c]
+        assert np.abs(got - x @ wc).max() <= 1e-5 * np.abs(x @ wc).max(), ("cross", c)
+    xb = _b_frags(x)
+    for ti, t in enumerate(tasks):
+        w1, b1 = f64(f"prediction_heads.{t}.0.weight"), f64(f"prediction_heads.{t}.0.bias")
+        w2 = f64(f"prediction_heads.{t}.3.weight")
+        acc2 = [np.zeros((32, 32), F) for _ in range(2)]
+        for tt in range(8):
+            acc1 = np.zeros((32, 32), F)
+            for u in range(16):
+                a = st.read(2)
+                acc1 += _mfma(a[0] + a[1], xb[u])
+            hrows = np.maximum(acc1.T / p.x3.sw_h1 + b1[32 * tt:32 * tt + 32][None, :], 0)
+            hb = np.zeros((2, 64, 8), F)
+            for sp in range(2):
+                for h in range(2):
+                    for j in range(8):
+                        hb[sp, 32 * h:32 * h + 32, j] = hrows[:, _acc_layout_feature(0, 8 * sp + j, h)]
+            for sp in range(2):
+                a = st.read(4)
+                acc2[0] += _mfma(a[0] + a[1], hb[sp])
+                acc2[1] += _mfma(a[2] + a[3], hb[sp])
+        got = _tile_to_rows(acc2) / p.x3.sw_h2
+        ref = np.maximum(x @ w1.T + b1, 0) @ w2.T
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), ("head", t)
+    assert st.pos == stream.shape[0]                 # the whole stream was consumed, nothing left over
+
+
+def test_plane_split_is_22_bit_accurate_and_in_fp16_range():
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal((64, 32)) * 10.0 ** rng.uniform(-6, 2, (64, 32))
+    s = weights.x3_pow2_scale(np.abs(w).max())
+    assert 2 ** 12 <= np.abs(w).max() * s < 2 ** 13 and np.log2(s) == int(np.log2(s))
+    fr = weights.x3_frags(w.astype(np.float32).astype(np.float64), s).view(np.float16).astype(np.float64)
+    assert np.isfinite(fr).all()
+    # undo the fragment layout: tile, ks, plane, lane = p + 32 half, j  ->  W[32 tile + p][16 ks + src(8 half + j)]
+    rec = np.zeros((64, 32))
+    for tile in range(2):
+        for ks in range(2):
+            for lane in range(64):
+                for j in range(8):
+                    pos = 8 * (lane >> 5) + j
+                    src = (pos & 3) | (((pos >> 3) & 1) << 2) | (((pos >> 2) & 1) << 3)
+                    rec[32 * tile + (lane & 31), 16 * ks + src] = fr[tile, ks, 0, lane, j] + fr[tile, ks, 1, lane, j]
+    w32 = w.astype(np.float32).astype(np.float64)
+    err = np.abs(rec / s - w32)
+    big = np.abs(w32) * s >= 2.0 ** -3                   # elements whose low plane is a normal fp16 number
+    assert (err[big] <= 2.0 ** -22 * np.abs(w32[big])).all()
+    assert (err[~big] <= 2.0 ** -25 / s).all()
