@@ -38,6 +38,7 @@ TOP_K = 10
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
 BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 X6_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6   # "x6" kernels: 6 bf16 MFMA products per fp32 multiply-add (gemm_core.hpp)
+X3_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 3   # "x3" kernel: 3 fp16 MFMA products per fp32 multiply-add (rowowner.hpp); fp16 rate == bf16 rate
 HBM_PEAK_GBS = 8000.0
 
 
@@ -271,11 +272,14 @@ def main():
             achieved = p["flops"] / p["launches"] / (avg_ms * 1e-3) / 1e12
             tr = pmc_traffic(name, list(prof))
             x6 = name.endswith("_x6")       # fp32 GEMM computed as 6 bf16-MFMA products per MAC (exact 3-way split)
-            peak = X6_PEAK_TFLOPS if x6 else FP32_PEAK_TFLOPS
+            x3 = name.endswith("_x3")       # fp32 chain computed as 3 fp16-MFMA products per MAC (two-plane split)
+            peak = X3_PEAK_TFLOPS if x3 else (X6_PEAK_TFLOPS if x6 else FP32_PEAK_TFLOPS)
             roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                        "peak_note": ("fp32-equivalent FLOPs (2*M*N*K) against dense bf16 MFMA peak / 6 products; "
-                                      f"the fp32 MFMA peak is {FP32_PEAK_TFLOPS}") if x6 else "fp32 MFMA peak",
+                        "peak_note": ("fp32-equivalent FLOPs (2*M*N*K of every GEMM of the chain) against dense fp16 MFMA peak "
+                                      f"/ 3 products = executed-MFMA utilisation; the fp32 MFMA peak is {FP32_PEAK_TFLOPS}") if x3
+                        else (("fp32-equivalent FLOPs (2*M*N*K) against dense bf16 MFMA peak / 6 products; "
+                               f"the fp32 MFMA peak is {FP32_PEAK_TFLOPS}") if x6 else "fp32 MFMA peak"),
                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                         "traffic_source": tr["source"] if tr else None,
                         "alg_bytes_per_launch": round(p["bytes"] / p["launches"]),
@@ -317,10 +321,10 @@ def main():
                 "step_ms_p95": round(step_ms[min(len(step_ms) - 1, int(np.ceil(0.95 * len(step_ms))) - 1)], 3),
                 "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "arithmetic": ("fp32 in / fp32 out everywhere; ranker GEMMs of > 8192 rows: operands split exactly into 3 "
-                               "bf16 planes, 6 bf16-MFMA products per MAC, fp32 accumulate (error at the fp32 fma-chain "
-                               "level, tools/x6_probe.hip); search: bf16-MFMA prefilter, fp32 re-score, certified exact; "
-                               "everything else fp32 MFMA / fp32 VALU"),
+                "arithmetic": ("fp32 in / fp32 out everywhere; ranker passes of > 8192 rows (engine " + rk.gemm_engine + "): "
+                               "operands scaled by powers of two and split into 2 fp16 planes, 3 fp16-MFMA products per MAC, "
+                               "fp32 accumulate (logit error vs float64 = 2x the fp32-MFMA engine's, profiles/r02_accuracy.json); "
+                               "search: bf16-MFMA prefilter, fp32 re-score, certified exact; everything else fp32 MFMA / fp32 VALU"),
                 "config": {"workload": ("configs[2]: 1M synthetic ads d=256, UserTower batch=512/GPU, "
                                         "exact IP top-500, TransformerRanker(256,8 heads,3 layers) on 500 cands, top-10")
                            if default_cfg else f"{n_ads} ads, index={args.index}"

@@ -630,7 +630,8 @@ static RankerWs ranker_ws(const amdrec_ranker_params* p, long long rows, long lo
     size_t o = 0;
     w.off_x = o;  o = align_up(o + dm, 256);
     w.off_t = o;  o = align_up(o + dm, 256);
-    w.off_x0 = o; o = align_up(o + dm, 256);
+    // X0 doubles as the row-owner engine's x0 scratch, which is addressed in whole 128-row workgroups
+    w.off_x0 = o; o = align_up(o + (size_t)((w.chunk + 127) / 128 * 128) * p->d_model * 4, 256);
     w.off_h = o;  o = align_up(o + (size_t)w.chunk * hw * 4, 256);
     w.off_u = o;  o = align_up(o + (size_t)(n_users > 0 ? n_users : 0) * p->d_model * 4, 256);
     w.bytes = o;
@@ -759,8 +760,7 @@ extern "C" int amdrec_ranker_forward(const amdrec_ranker_params* p, const int64_
         g.rows = m; g.F = F; g.F0 = F0; g.E = p->emb_dim; g.eshift = ilog2(p->emb_dim);
         g.n_num = p->n_num; g.cat0_rowdiv = (int)user_rowdiv;
         // fp16x3 row-owner engine: the rest of the chain is one kernel; with the candidate-side cache it also does the
-        // gather (x0 = cache row + user half).  Its x0 scratch is the X0 region (+ up to 127 padding rows, which run into
-        // the H region behind it: unused on this path and at least 4x as large).
+        // gather (x0 = cache row + user half).  Its x0 scratch is the X0 region (sized in whole 128-row workgroups).
         const bool use_x3 = ranker_x3_wanted(p, m);
         if (use_x3 && hoist && p->ad_proj_cache) {
             int rc3 = ranker_x3_run(p, nullptr, 0, (const float*)U, (const long long*)ad_rowmap, r0, (int)user_rowdiv,
