@@ -4,59 +4,6 @@
 #include "rowowner.hpp"
 #include "../../include/amdrec.h"
 
-namespace amdrec {
-namespace x3 {
-
-__global__ __launch_bounds__(256, 1) void ranker_x3_kernel(Program G, Input in, long long rows, float* scratch,
-                                                           float* x_out, long long ld_xout, float* logits,
-                                                           long long ld_logits) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, q = lane & 31;
-    const long long row = (long long)blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE + q;
-    const bool row_ok = row < rows;
-    const long long rowc = row_ok ? row : rows - 1;                 // clamped: branch-free loads, stores are guarded
-
-    Ring ring;
-    ring.start(G.stream, G.total_chunks, (lds_byte*)smem, wave, lane);
-
-    f32x16 x[8];
-    if (in.X != nullptr) {
-        load_rows(x, in.X + rowc * in.ldx, h);
-    } else {
-        const long long gr = in.row_base + rowc;
-        long long a = in.rowmap ? in.rowmap[gr] : gr;
-        a = a < 0 ? 0 : (a >= in.n_cache ? in.n_cache - 1 : a);     // clamped like the gather loader (reported separately)
-        load_rows(x, in.cache + a * in.ldc, h);
-        add_rows(x, in.U + (gr / in.rowdiv) * 256, h);              // cache row + the user's half (same order as proj_gather)
-    }
-    float* x0_row = scratch + row * 256;                            // this lane's own row (scratch is padded to whole workgroups)
-    bool x0_saved = false;
-    for (int p = 0; p < G.n_phases; ++p) {
-        const Phase& P = G.ph[p];
-        const int type = __builtin_amdgcn_readfirstlane(P.type);
-        if (type == PH_ATTN_LN) {
-            phase_attn_ln(ring, P, x, h);
-        } else if (type == PH_FFN_LN) {
-            phase_ffn_ln(ring, P, x, h);
-        } else if (type == PH_CROSS) {
-            if (!x0_saved) {                                        // x0 = the encoder output, kept for all cross layers
-                store_rows(x, x0_row, h);
-                x0_saved = true;
-            }
-            phase_cross(ring, P, x, x0_row, h);
-        } else {
-            phase_heads(ring, G, P, x, logits, ld_logits, row, row_ok, h);
-        }
-    }
-    if (x_out != nullptr && row_ok) store_rows(x, x_out + row * ld_xout, h);
-    ring.drain();                                                   // no LDS-DMA may land after the workgroup's LDS is released
-}
-
-}  // namespace x3
-}  // namespace amdrec
-
 using namespace amdrec;
 
 // eligibility of the engine for these parameters (the reference architecture: d_model 256, 64-wide head layer 2)

@@ -50,9 +50,12 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr int FRAG_BYTES = 1024;                 // one fragment set: 64 lanes x 8 fp16
 constexpr int CHUNK_FRAGS = 16;
 constexpr int CHUNK_BYTES = CHUNK_FRAGS * FRAG_BYTES;
-constexpr int NBUF = 8;                          // ring chunks (128 KB)
+#ifndef AMDREC_X3_NBUF
+#define AMDREC_X3_NBUF 8
+#endif
+constexpr int NBUF = AMDREC_X3_NBUF;             // ring chunks (8 x 16 KB = 128 KB)
 constexpr int RING_BYTES = NBUF * CHUNK_BYTES;
-constexpr int DEPTH = 5;                         // chunks in flight beyond the certified one (NBUF >= DEPTH + 3)
+constexpr int DEPTH = NBUF - 3;                  // chunks in flight beyond the certified one (NBUF >= DEPTH + 3)
 constexpr int ROWS_PER_WAVE = 32, WAVES = 4, ROWS_PER_WG = ROWS_PER_WAVE * WAVES;
 constexpr int TARGET_EXP = 12;                   // scaled row / matrix maxima lie in [2^12, 2^13)
 
@@ -110,6 +113,13 @@ __device__ __forceinline__ f32x4 param4(const float* p, int f0, int g, int h) {
 // ---- the ring --------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
+// Elimination switches for tools/x3_probe.hip (0 in the product): 1 = no weight DMA and no wait for it, 2 = no
+// per-chunk barrier, 4 = no fragment reads from LDS (stale registers), 8 = no hidden-tile conversion (stale planes).
+#ifndef AMDREC_X3_DBG
+#define AMDREC_X3_DBG 0
+#endif
+constexpr int DBG = AMDREC_X3_DBG;
+
 struct Ring {
     const unsigned char* gsrc;   // stream + wave * 4 KB + lane * 16 (per lane)
     lds_byte* lds_dma;           // ring + wave * 4 KB (wave-uniform: the DMA adds lane * 16 itself)
@@ -120,6 +130,7 @@ struct Ring {
     int rfrags;                  // fragment sets read so far
 
     __device__ __forceinline__ void issue() {
+        if (DBG & 1) { ++issued; return; }
         const int c = issued < total ? issued : total - 1;        // past the end: harmless re-load of the last chunk into a free slot
         const unsigned char* src = gsrc + (size_t)c * CHUNK_BYTES;
         lds_byte* dst = lds_dma + (uint32_t)(issued % NBUF) * CHUNK_BYTES;
@@ -133,8 +144,8 @@ struct Ring {
     // younger DMAs may still be in flight), everyone's share after the barrier; then refill the slot of the chunk
     // two behind (every wave has issued all MFMAs that consumed it: it is past that chunk's last fragment read).
     __device__ __forceinline__ void certify_next() {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DEPTH - 1)) : "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(DBG & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DEPTH - 1)) : "memory");
+        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
         issue();
     }
     __device__ __forceinline__ void start(const unsigned char* stream, int total_chunks, lds_byte* lds, int wave, int lane) {
@@ -155,10 +166,16 @@ struct Ring {
     __device__ __forceinline__ void read(f16x8 (&f)[N]) {
         if ((rfrags & (CHUNK_FRAGS - 1)) == 0) certify_next();     // first read of a chunk: certify the one after it
         const lds_byte* a = lds_rd + rpos;
+        if ((DBG & 4) && rfrags != 0) {
 #pragma unroll
-        for (int u = 0; u < N; ++u)
-            f[u] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(a + u * FRAG_BYTES);
-        rpos = (rpos + N * FRAG_BYTES) & (RING_BYTES - 1);
+            for (int u = 0; u < N; ++u) asm volatile("" : "+v"(f[u]));   // whatever the registers hold
+        } else {
+#pragma unroll
+            for (int u = 0; u < N; ++u)
+                f[u] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(a + u * FRAG_BYTES);
+        }
+        rpos += N * FRAG_BYTES;
+        if (rpos >= RING_BYTES) rpos -= RING_BYTES;
         rfrags += N;
     }
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -299,6 +316,10 @@ __device__ __forceinline__ void phase_attn_ln(Ring& ring, const Phase& P, f32x16
 
 // ---- hidden tile -> planes: H = relu(acc1) * c (c = hidden scale / (2^sw1 * row scale)), clamped below the fp16 maximum
 __device__ __forceinline__ void hidden_planes(const f32x16& a1, float c, f16x8 (&hh)[2], f16x8 (&hl)[2]) {
+    if (DBG & 8) {
+        asm volatile("" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hl[0]), "+v"(hl[1]) : "v"(a1));
+        return;
+    }
     f32x16 t;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = fminf(fmaxf(a1[r], 0.f) * c, 60000.f);
@@ -474,6 +495,54 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
         dot += __shfl_xor(dot, 32, 64);
         if (h == 0 && row_ok) out[(long long)task * ld_out + row] = dot + G.hb3[task][0];
     }
+}
+
+// ---- the kernel: input rows (dense X or cached-projection gather) -> all phases of the chain -> logits ---------------
+__global__ __launch_bounds__(256, 1) void ranker_x3_kernel(Program G, Input in, long long rows, float* scratch,
+                                                           float* x_out, long long ld_xout, float* logits,
+                                                           long long ld_logits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, q = lane & 31;
+    const long long row = (long long)blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE + q;
+    const bool row_ok = row < rows;
+    const long long rowc = row_ok ? row : rows - 1;                 // clamped: branch-free loads, stores are guarded
+
+    Ring ring;
+    ring.start(G.stream, G.total_chunks, (lds_byte*)smem, wave, lane);
+
+    f32x16 x[8];
+    if (in.X != nullptr) {
+        load_rows(x, in.X + rowc * in.ldx, h);
+    } else {
+        const long long gr = in.row_base + rowc;
+        long long a = in.rowmap ? in.rowmap[gr] : gr;
+        a = a < 0 ? 0 : (a >= in.n_cache ? in.n_cache - 1 : a);     // clamped like the gather loader (reported separately)
+        load_rows(x, in.cache + a * in.ldc, h);
+        add_rows(x, in.U + (gr / in.rowdiv) * 256, h);              // cache row + the user's half (same order as proj_gather)
+    }
+    float* x0_row = scratch + row * 256;                            // this lane's own row (scratch is padded to whole workgroups)
+    bool x0_saved = false;
+    for (int p = 0; p < G.n_phases; ++p) {
+        const Phase& P = G.ph[p];
+        const int type = __builtin_amdgcn_readfirstlane(P.type);
+        if (type == PH_ATTN_LN) {
+            phase_attn_ln(ring, P, x, h);
+        } else if (type == PH_FFN_LN) {
+            phase_ffn_ln(ring, P, x, h);
+        } else if (type == PH_CROSS) {
+            if (!x0_saved) {                                        // x0 = the encoder output, kept for all cross layers
+                store_rows(x, x0_row, h);
+                x0_saved = true;
+            }
+            phase_cross(ring, P, x, x0_row, h);
+        } else {
+            phase_heads(ring, G, P, x, logits, ld_logits, row, row_ok, h);
+        }
+    }
+    if (x_out != nullptr && row_ok) store_rows(x, x_out + row * ld_xout, h);
+    ring.drain();                                                   // no LDS-DMA may land after the workgroup's LDS is released
 }
 
 }  // namespace x3

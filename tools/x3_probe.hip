@@ -1,0 +1,74 @@
+// Elimination runs of the row-owner kernel (csrc/rowowner.hpp): the product kernel compiled with AMDREC_X3_DBG switches,
+// timed on the full chain (3 encoder layers, 3 cross, 3 heads) over 256000 synthetic rows.  Numerics are meaningless
+// here (random fragment bits); only time is read.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DAMDREC_X3_DBG=<bits> tools/x3_probe.hip -o tools/bin/x3_probe_<bits>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../movie-recommender-demo_amd/csrc/rowowner.hpp"
+using namespace amdrec;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const long long rows = argc > 1 ? atoll(argv[1]) : 256000;
+    const int L = 3, C = 3, T = 3, dff = 1024, h1 = 256;
+    const long long chunks = L * (16 + 4ll * (dff / 32)) + 16ll * C + (long long)T * (h1 / 32) * 40 / 16;
+    std::vector<uint16_t> st((size_t)chunks * 8192);
+    srand(1);
+    for (auto& v : st) {   // fp16 with exponent in [2^4, 2^11], random sign and mantissa
+        const uint16_t e = 15 + 4 + rand() % 8;
+        v = (uint16_t)(((rand() & 1) << 15) | (e << 10) | (rand() & 0x3ff));
+    }
+    uint16_t* dstream; float *dX, *dpar, *dscratch, *dlog;
+    CK(hipMalloc(&dstream, st.size() * 2));
+    CK(hipMemcpy(dstream, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+    std::vector<float> X((size_t)rows * 256);
+    for (auto& v : X) v = (float)(rand() % 2001 - 1000) / 500.f;
+    CK(hipMalloc(&dX, X.size() * 4));
+    CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> par(4096, 0.01f);
+    for (int i = 2048; i < 4096; ++i) par[i] = 1.0f;     // gamma
+    CK(hipMalloc(&dpar, par.size() * 4));
+    CK(hipMemcpy(dpar, par.data(), par.size() * 4, hipMemcpyHostToDevice));
+    const long long prow = (rows + 127) / 128 * 128;
+    CK(hipMalloc(&dscratch, (size_t)prow * 1024));
+    CK(hipMalloc(&dlog, (size_t)rows * 4 * 4));
+    x3::Program G{};
+    int n = 0;
+    const float sw = 65536.f * 64.f;     // packed weights ~2^10 -> real ~2^-12 .. 2^-5
+    for (int l = 0; l < L; ++l) {
+        x3::Phase& A = G.ph[n++];
+        A.type = x3::PH_ATTN_LN; A.b1 = dpar; A.gamma = dpar + 2048; A.beta = dpar; A.sw1 = sw; A.sw2 = 1; A.ln_eps = 1e-5f;
+        x3::Phase& F = G.ph[n++];
+        F.type = x3::PH_FFN_LN; F.n_steps = dff / 32; F.b1 = dpar; F.b2 = dpar; F.gamma = dpar + 2048; F.beta = dpar;
+        F.sw1 = sw; F.sw2 = sw; F.hn = 16.f * 0.5f; F.hb = 0.01f; F.ln_eps = 1e-5f;
+    }
+    for (int c = 0; c < C; ++c) { x3::Phase& P = G.ph[n++]; P.type = x3::PH_CROSS; P.b1 = dpar; P.sw1 = sw; P.sw2 = 1; }
+    x3::Phase& H = G.ph[n++];
+    H.type = x3::PH_HEADS; H.n_steps = h1 / 32; H.n_tasks = T; H.b1 = dpar; H.sw1 = sw; H.sw2 = sw; H.hn = 8.f; H.hb = 0.01f;
+    for (int t = 0; t < T; ++t) { G.hb2[t] = dpar; G.hw3[t] = dpar; G.hb3[t] = dpar; }
+    G.n_phases = n; G.total_chunks = (int)chunks; G.stream = (const unsigned char*)dstream;
+    x3::Input in{};
+    in.X = dX; in.ldx = 256;
+    CK(hipFuncSetAttribute((const void*)x3::ranker_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES));
+    const unsigned grid = (unsigned)((rows + 127) / 128);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
+    CK(hipDeviceSynchronize());
+    const int reps = 10;
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double flop = 2.0 * rows * (L * (65536.0 + 2 * 262144.0) + C * 65536.0 + T * (65536.0 + 16384.0 + 64.0));
+    printf("DBG=%d rows=%lld: %.3f ms  %.1f TF fp32-equivalent  (%.3f of 833 TF)\n", AMDREC_X3_DBG, rows, ms, flop / ms / 1e9,
+           flop / ms / 1e9 / 833.3);
+    return 0;
+}
