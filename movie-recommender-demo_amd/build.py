@@ -74,9 +74,60 @@ def build(force=False, verbose=False):
     return LIB
 
 
+SAN_LIB = os.path.join(OUT, "libamdrec_san.so")
+SAN_DRIVER = os.path.join(OUT, "abi_san_driver")
+SAN_FLAGS = ["-O1", "-g", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fsanitize=address,undefined",
+             "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-Wno-unused-function"]
+
+
+def build_sanitized(force=False):
+    """The same sources with the HOST side under AddressSanitizer + UBSan (device code is compiled normally: GPU ASan is
+    not available on this pool) -> lib/libamdrec_san.so, plus tests/abi_san_driver.cpp linked against it.  CPU box only:
+    the driver exercises argument validation / workspace arithmetic / error plumbing, never a kernel."""
+    os.makedirs(OUT, exist_ok=True)
+    root = os.path.dirname(HERE)
+    driver_src = os.path.join(root, "tests", "abi_san_driver.cpp")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers += [os.path.join(root, "include", "amdrec.h"), driver_src]
+    srcs = _sources()
+    stamp = os.path.join(OUT, "build_san.sha256")
+    digest = _digest(headers + [os.path.join(CSRC, s) for s in srcs]) + "|san"
+    if not force and os.path.exists(SAN_DRIVER) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return SAN_LIB, SAN_DRIVER
+
+    def comp(src):
+        obj = os.path.join(OUT, src + ".san.o")
+        return src, obj, subprocess.run([HIPCC, *SAN_FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj],
+                                        capture_output=True, text=True)
+    objs = []
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        for src, obj, r in ex.map(comp, srcs):
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError(f"hipcc (sanitized) failed on {src}")
+            objs.append(obj)
+    r = subprocess.run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fsanitize=address,undefined",
+                        "-fno-gpu-sanitize", "-shared-libsan", "-o", SAN_LIB, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("link (sanitized) failed")
+    r = subprocess.run([HIPCC, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-gpu-sanitize",
+                        "-shared-libsan", "-fno-sanitize-recover=undefined", "-x", "c++", driver_src, "-x", "none",
+                        "-o", SAN_DRIVER, f"-L{OUT}", "-lamdrec_san", f"-Wl,-rpath,{OUT}"], capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("driver link failed")
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return SAN_LIB, SAN_DRIVER
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--sanitize", action="store_true", help="also build the ASan/UBSan host build + its driver")
     a = ap.parse_args()
     print(build(a.force, a.verbose))
+    if a.sanitize:
+        print(*build_sanitized(a.force))
