@@ -168,10 +168,41 @@ class TransformerRanker(nn.Module):
         return r
 
     # -- forward ----------------------------------------------------------------------
+    def autograd_forward(self, user_categorical, ad_categorical, numerical, mask=None):
+        """The reference's op sequence on ATen with autograd (transformer_ranker.py:310-380 with :59-88, :114, :148-153,
+        :199-203): used in train mode.  The LITERAL 8-head attention is kept here - with the attention-weight dropout
+        (:73) active the seq-len-1 softmax weight is 0 or 1/(1-p) per (row, head), not the constant 1 of eval mode."""
+        import math
+        F = torch.nn.functional
+        ue = torch.cat([e(user_categorical[:, i].long()) for i, e in enumerate(self.user_embeddings.values())], dim=1)
+        ae = torch.cat([e(ad_categorical[:, i].long()) for i, e in enumerate(self.ad_embeddings.values())], dim=1)
+        x = self.feature_projection(torch.cat([ue, ae, numerical], dim=1)).unsqueeze(1)        # :328, :355-358
+        x = self.dropout(x + self.positional_encoding[:, :1, :])                                # :361-362
+        for layer in self.transformer_layers:
+            at = layer.self_attention
+            B = x.size(0)
+            q = at.W_q(x).view(B, -1, at.num_heads, at.d_k).transpose(1, 2)
+            k = at.W_k(x).view(B, -1, at.num_heads, at.d_k).transpose(1, 2)
+            v = at.W_v(x).view(B, -1, at.num_heads, at.d_k).transpose(1, 2)
+            scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(at.d_k)
+            if mask is not None:
+                scores = scores.masked_fill(mask == 0, -1e9)
+            w = at.dropout(F.softmax(scores, dim=-1))
+            ctx = torch.matmul(w, v).transpose(1, 2).contiguous().view(B, -1, at.d_model)
+            x = layer.norm1(x + layer.dropout1(at.W_o(ctx)))                                    # :148-149
+            ff = layer.feed_forward
+            x = layer.norm2(x + layer.dropout2(ff.fc2(ff.dropout(F.relu(ff.fc1(x))))))           # :114, :152-153
+        x = x.squeeze(1)
+        fi = self.feature_interaction
+        x0, xl = x, x
+        for i in range(fi.num_crosses):
+            xl = fi.dropout(x0 * (torch.matmul(xl, fi.cross_weights[i]) + fi.cross_biases[i]) + xl)   # :201-202
+        return {t: head(xl).squeeze(1) for t, head in self.prediction_heads.items()}            # :375-378
+
     def _run(self, user_cat, numerical, user_rowdiv, ad_cat, ad_rowmap, rows, check_indices=True, raw=False,
              use_cache=False):
         if self.training:
-            raise NotImplementedError("the HIP forward implements eval() semantics only; call .eval()")
+            raise NotImplementedError("score_candidates / the HIP forward implement eval() semantics only; call .eval()")
         dev = ad_cat.device
         params, tasks = self._pack(dev)
         cache = self._cache_for(ad_cat) if use_cache else None
@@ -194,7 +225,10 @@ class TransformerRanker(nn.Module):
         return (tasks, logits) if raw else {t: logits[i] for i, t in enumerate(tasks)}
 
     def forward(self, user_categorical, ad_categorical, numerical, mask: Optional[torch.Tensor] = None):
-        """transformer_ranker.py:332-380 -> {'ctr','engagement','revenue'}: logits [B]."""
+        """transformer_ranker.py:332-380 -> {'ctr','engagement','revenue'}: logits [B].  train() mode: the same network
+        in stock PyTorch autograd (``autograd_forward``), for amdrec.training."""
+        if self.training:
+            return self.autograd_forward(user_categorical, ad_categorical, numerical, mask)
         uc = _lib.require_gpu(user_categorical, "user_categorical").long().contiguous()
         ac = _lib.require_gpu(ad_categorical, "ad_categorical").long().contiguous()
         nm = _lib.require_gpu(numerical, "numerical").to(torch.float32).contiguous()
@@ -221,5 +255,15 @@ class TransformerRanker(nn.Module):
             raise ValueError("one user row per candidate list expected")
         return self._run(uc, nm, k, table, cand.view(-1), U * k, check_indices, raw, use_cache=True)
 
-    def compute_loss(self, *a, **k):
-        raise NotImplementedError("training (transformer_ranker.py:382-415) is outside the MI355X hot path")
+    def compute_loss(self, predictions, labels, task_weights=None):
+        """transformer_ranker.py:382-415: weighted sum of per-task BCE-with-logits -> (total, dict of floats)."""
+        if task_weights is None:
+            task_weights = {"ctr": 1.0, "engagement": 0.5, "revenue": 0.3}
+        losses, total = {}, 0
+        for task in predictions.keys():
+            if task in labels:
+                tl = torch.nn.functional.binary_cross_entropy_with_logits(predictions[task], labels[task].float())
+                losses[f"{task}_loss"] = tl.item()
+                total = total + task_weights.get(task, 1.0) * tl
+        losses["total_loss"] = total.item()
+        return total, losses

@@ -7,8 +7,10 @@ its checkpoints (``model_state_dict`` or bare ``state_dict``, inference.py:99-10
     user_tower.embedding_layer.embeddings.<col>.weight [card,16]
     user_tower.mlp.{0,4,8}.{weight,bias}, user_tower.mlp.{1,5}.{weight,bias,running_mean,
     running_var,num_batches_tracked}; ad_tower.* likewise.
-Training (compute_loss, two_tower_model.py:256-285) is outside the hot path: the HIP forward
-has eval semantics (BatchNorm running stats, Dropout identity) and refuses train mode.
+Training: in ``train()`` mode the forward is the reference's own op sequence in stock
+PyTorch autograd on the module's device (BatchNorm batch statistics, Dropout active) - the hand-written HIP
+kernels are the eval-mode hot path only; ``compute_loss`` is two_tower_model.py:256-285 and the trainers live in
+``amdrec.training``.  A weight update re-packs the HIP weights on the next eval-mode call (parameter versions).
 """
 from __future__ import annotations
 
@@ -62,10 +64,18 @@ class _Tower(nn.Module):
             self._packed = (key, params, keep)
         return self._packed[1]
 
+    def autograd_forward(self, cat: torch.Tensor, num: torch.Tensor = None) -> torch.Tensor:
+        """The reference's op sequence on ATen with autograd (two_tower_model.py:33-49, :110-119 / :176-182): used in
+        train mode, where BatchNorm takes batch statistics and Dropout is active."""
+        embs = [emb(cat[:, i].long()) for i, emb in enumerate(self.embedding_layer.embeddings.values())]   # :43-44
+        x = torch.cat(embs, dim=1)                                                                         # :47
+        if self._n_num:
+            x = torch.cat([x, num], dim=1)                                                                 # :113
+        return torch.nn.functional.normalize(self.mlp(x), p=2, dim=1)                                      # :116-119
+
     def encode(self, cat: torch.Tensor, num: torch.Tensor = None, check_indices: bool = True) -> torch.Tensor:
         if self.training:
-            raise NotImplementedError("the HIP forward implements eval() semantics only; call .eval() "
-                                      "(training is outside the MI355X hot path)")
+            return self.autograd_forward(cat, num)
         cat = _lib.require_gpu(cat, "categorical_features")
         dev = cat.device
         if cat.dim() != 2 or cat.shape[1] != len(self._names):
@@ -139,8 +149,11 @@ class TwoTowerModel(nn.Module):
         u, a = self.forward(user_categorical, user_numerical, ad_categorical)
         return (u * a).sum(dim=1)
 
-    def compute_loss(self, *a, **k):
-        raise NotImplementedError("training (two_tower_model.py:256-285) is outside the MI355X hot path")
+    def compute_loss(self, user_embeddings: torch.Tensor, ad_embeddings: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """two_tower_model.py:256-285: in-batch softmax cross-entropy at ``self.temperature`` (diagonal = positives; the
+        reference builds a positive mask from ``labels`` and never uses it)."""
+        sim = torch.matmul(user_embeddings, ad_embeddings.T) / self.temperature
+        return torch.nn.functional.cross_entropy(sim.view(-1, sim.size(1)), torch.arange(sim.size(0), device=sim.device))
 
     def load_state_dict(self, state_dict, *a, **k):
         r = super().load_state_dict(state_dict, *a, **k)

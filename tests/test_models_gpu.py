@@ -193,7 +193,7 @@ def test_ranker_ad_projection_cache_is_bit_identical_and_invalidates():
         assert torch.equal(upd[t], again[t]), t
 
 
-def test_bad_index_raises_like_torch_and_train_mode_refused():
+def test_bad_index_raises_like_torch_and_no_cpu_fallback():
     m, sd, (user, ad, nnum), _ = _two_tower("demo")
     uc, un = synth.user_batch(user, nnum, 4, seed=1)
     uc[2, 1] = 100                                # card is 100
@@ -208,9 +208,9 @@ def test_bad_index_raises_like_torch_and_train_mode_refused():
     acr[3, 19] = 200
     with pytest.raises(IndexError):
         r(_cu(ucr), _cu(acr), _cu(unr))
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m.get_ad_embeddings(_cu(synth.ad_features(ad, 2, seed=3)))
+    r.train()
+    with pytest.raises(NotImplementedError):                   # score_candidates is the eval-mode HIP pipeline entry only
+        r.score_candidates(_cu(ucr[:1]), _cu(unr[:1]), _cu(np.zeros((1, 4), np.int64)), _cu(acr))
     from amdrec import _lib
     with pytest.raises(_lib.AmdrecError):
         m.eval().get_ad_embeddings(torch.zeros((2, 20), dtype=torch.int64))   # CPU tensor: no fallback
