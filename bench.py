@@ -207,9 +207,12 @@ def main():
     corpus_kind = args.corpus or ("clustered" if args.index == "ivf" else "random")
     shard = device_corpus(n_ads, DIM, device, row0=row0, rows=rows, kind=corpus_kind)
     if args.index == "ivf":
-        # each rank is an independent IVF index over its rows: nlist/world lists, nprobe/world probes per rank
-        index = FAISSIndex(DIM, index_type="IVF", nlist=max(1, args.nlist // world),
-                           nprobe=max(1, args.nprobe // world), device=device)
+        # ONE coarse quantizer for the whole corpus (nlist lists, nprobe probes), shared by all ranks: rank 0 trains on
+        # its shard and broadcasts the centroids, every rank files its rows under them (its slice of every list), so
+        # the merged result is exactly the unsharded IVF result (amdrec.sharded)
+        from amdrec.sharded import share_ivf_centroids
+        index = FAISSIndex(DIM, index_type="IVF", nlist=args.nlist, nprobe=args.nprobe, device=device)
+        share_ivf_centroids(index, shard, rank, world)
     else:
         index = FAISSIndex(DIM, index_type="Flat", device=device)
     index.add(shard)                                        # renormalises + stores (faiss_retrieval.py:97-127)
@@ -291,7 +294,9 @@ def main():
                        "launches_per_step": v["launches"] / args.steps} for k, v in sorted(prof.items())}
         sf = next((v for k, v in prof.items() if k.startswith("search_filter")), None)
         search = None
-        if sf:
+        if args.index == "ivf":
+            search = ivf_search_stats(index, flat_ref, tt, uc, un, prof, args.steps)
+        elif sf:
             ms = sf["total_ms"] / sf["launches"]
             mixed = getattr(index, "_mixed", False)      # bf16 shadow corpus read by the filter pass
             eb = 2 if mixed else 4
@@ -327,26 +332,51 @@ def main():
                                "search: bf16-MFMA prefilter, fp32 re-score, certified exact; everything else fp32 MFMA / fp32 VALU"),
                 "config": {"workload": ("configs[2]: 1M synthetic ads d=256, UserTower batch=512/GPU, "
                                         "exact IP top-500, TransformerRanker(256,8 heads,3 layers) on 500 cands, top-10")
-                           if default_cfg else f"{n_ads} ads, index={args.index}"
+                           if default_cfg else f"{n_ads} ads ({corpus_kind} corpus), index={args.index}"
                            + (f" nlist={args.nlist} nprobe={args.nprobe}" if args.index == "ivf" else ""),
                            "n_ads": n_ads, "dim": DIM, "users_per_step": B_global, "stage1_k": STAGE1_K,
                            "top_k": TOP_K, "corpus_rows_per_gpu": rows,
                            "parallelism": f"corpus row-sharded x{world}, ranker data-parallel over users"},
                 "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "kernels": kernels, "search": search}
         print(json.dumps(line), flush=True)
-    if flat_ref is not None and world == 1 and rank == 0:
-        emb = tt.get_user_embeddings(uc, un)
-        a, _ = index.search_device(emb, STAGE1_K)
-        b, _ = flat_ref.search_device(emb, STAGE1_K)
-        a, b = a.cpu().numpy(), b.cpu().numpy()
-        rec_at_k = float(np.mean([len(set(x) & set(y)) / STAGE1_K for x, y in zip(a, b)]))
-        print(json.dumps({"ivf_recall_at_500_vs_flat": round(rec_at_k, 4), "nlist": index.nlist,
-                          "nprobe": index.nprobe, "n_ads": n_ads}), file=sys.stderr, flush=True)
     if args.sweep and rank == 0 and world == 1:
         latency_sweep(rec, uc, un, device)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ivf_search_stats(index, flat_ref, tt, uc, un, prof, steps):
+    """IVF arm: recall@500 against the exact Flat result on this rank's rows, and the scan priced against HBM with the
+    bytes it must read: every probed list once per 64-query group (1 KiB per row), from the probes of the timed batch."""
+    from amdrec.index import flat_search
+    emb = tt.get_user_embeddings(uc, un)
+    qn = emb / emb.norm(dim=1, keepdim=True).clamp_min(1e-30)
+    st = index._ivf
+    nq, nprobe = qn.shape[0], index.nprobe
+    cs = torch.empty((nq, nprobe), dtype=torch.float32, device=qn.device)
+    probes = torch.empty((nq, nprobe), dtype=torch.int64, device=qn.device)
+    flat_search(st.centroids, st.nlist, qn.contiguous(), nprobe, cs, probes)
+    _, _, _, lens, max_len, _ = st._build_lists(index._xb, index._n)
+    cnt = torch.bincount(probes[probes >= 0].reshape(-1), minlength=st.nlist)
+    scan_rows = int(((cnt + 63) // 64 * lens).sum().item())
+    per_query = float(lens[probes.clamp_min(0)].sum(1).float().mean().item())
+    out = {"engine": f"IVF-Flat nlist={index.nlist} nprobe={nprobe} (coarse fp32-MFMA top-{nprobe} over the centroids, "
+                     "grouped fp32-MFMA list scan, exact k-select)",
+           "rows_scanned_per_query": round(per_query, 1), "scan_alg_bytes_per_step": scan_rows * DIM * 4,
+           "list_len_min_mean_max": [int(lens.min().item()), round(float(lens.float().mean().item()), 1), int(max_len)]}
+    sc = next((v for k, v in prof.items() if k.startswith("ivf_scan")), None)
+    if sc and sc["total_ms"]:
+        ms = sc["total_ms"] / steps
+        out["scan_ms"] = round(ms, 3)
+        out["scan_alg_GBps"] = round(scan_rows * DIM * 4 / ms / 1e6, 1)
+        out["scan_hbm_frac"] = round(scan_rows * DIM * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)
+    if flat_ref is not None:
+        a, _ = index.search_device(emb, STAGE1_K)
+        b, _ = flat_ref.search_device(emb, STAGE1_K)
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        out["recall_at_500_vs_flat"] = round(float(np.mean([len(set(x) & set(y)) / STAGE1_K for x, y in zip(a, b)])), 4)
+    return out
 
 
 def latency_sweep(rec, uc, un, device, reps=30):

@@ -88,6 +88,25 @@ int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, const int64
 int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count /*[nq]*/,
                       int64_t nq, int k, float* out_scores /*[nq][k]*/, int64_t* out_pos /*[nq][k]*/,
                       void* stream);
+/* Step 2 as kernels (no host sync, capturable): from probes[nq][nprobe] and the list lengths, the pool layout
+ * (pool_base[nq][nprobe], pool_count[nq]) and the (query, probe) pairs grouped by list for amdrec_ivf_scan_grouped
+ * (pair_query / pair_probe [nq*nprobe], group_off / qtile_prefix [nlist+1]; order inside a group is unspecified - it
+ * does not influence any result).  workspace: >= 4*(nlist+1) + 4*nq*nprobe + 512 bytes. */
+int amdrec_ivf_group(const int64_t* probes, int64_t nq, int nprobe, int nlist, const int64_t* list_len /*[nlist]*/,
+                     int64_t* pool_base, int64_t* pool_count, int64_t* pair_query, int64_t* pair_probe,
+                     int64_t* group_off, int64_t* qtile_prefix, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Index build (faiss IndexIVFFlat.train / .add behind FAISSIndex.train / .add, faiss_retrieval.py:83-95, :118).
+ * amdrec_ivf_assign: assign[r] = arg max_c <x[r], centroids[c]> (the IndexFlatIP quantizer; ties -> lower c;
+ * fp32 MFMA GEMM with an arg-max epilogue), best_score optional.  workspace: >= 8*rows + 256 bytes.
+ * amdrec_ivf_kmeans_step: one spherical Lloyd iteration in place: assign, per-centroid sum (64-bit fixed-point integer
+ * atomics: order-independent, so training is bit-reproducible), centroid = sum / |sum| (empty clusters keep theirs). */
+int amdrec_ivf_assign(const float* x, int64_t rows, int64_t ld, int dim, const float* centroids, int nlist,
+                      int64_t ld_centroids, int64_t* assign /*[rows]*/, float* best_score /*[rows] or NULL*/,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int amdrec_ivf_kmeans_workspace(int64_t rows, int dim, int nlist, size_t* bytes /*host*/);
+int amdrec_ivf_kmeans_step(const float* x, int64_t rows, int64_t ld, int dim, float* centroids /*in/out*/, int nlist,
+                           int64_t ld_centroids, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Cross-shard merge (absent in the single-device reference): for queries
  * [q0, q0+nq) merge n_lists per-shard top-k lists (scores/positions of list g start

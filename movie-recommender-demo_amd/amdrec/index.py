@@ -182,6 +182,26 @@ class FAISSIndex:
         self._trained = True
         self._log(f"Index trained in {time.time() - t0:.2f}s")
 
+    def set_trained_centroids(self, centroids):
+        """Install an already trained coarse quantizer (IVF): ``centroids`` [nlist, dimension], unit rows.  This is how
+        the ranks of a sharded index share ONE quantizer (amdrec.sharded.share_ivf_centroids) -
+        faiss would do the same with ``index_ivf.quantizer`` handed to every shard."""
+        if self.index_type != "IVF":
+            raise ValueError("only an IVF index has a coarse quantizer")
+        if self._n:
+            raise ValueError("set the centroids before adding vectors")
+        from . import ivf
+        c = self._to_device_f32(centroids)
+        if c.shape[0] != self.nlist:
+            raise ValueError(f"expected {self.nlist} centroids, got {c.shape[0]}")
+        self._ivf = ivf.IVFState(c)
+        self._trained = True
+
+    @property
+    def centroids(self):
+        """The trained coarse quantizer [nlist, dimension] (device tensor), or None."""
+        return None if self._ivf is None else self._ivf.centroids
+
     def add(self, embeddings, ad_ids: Optional[List] = None):
         """faiss_retrieval.py:97-127."""
         if not self._trained:

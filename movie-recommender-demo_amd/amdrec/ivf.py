@@ -1,14 +1,20 @@
 """IVF-Flat state for ``FAISSIndex(index_type='IVF')`` (faiss_retrieval.py:50-55): coarse centroids,
 list assignment, list-contiguous copy of the corpus, and the search driver over libamdrec's
-``amdrec_flat_search`` (coarse probes) + ``amdrec_ivf_scan`` + ``amdrec_ivf_select``.
+``amdrec_flat_search`` (coarse probes) + ``amdrec_ivf_group`` + ``amdrec_ivf_scan[_grouped]`` + ``amdrec_ivf_select``.
 
-Training (k-means) and assignment run at index-BUILD time with plain torch matmuls on the device
-(offline plumbing; the hot path - search - is hand-written HIP).  faiss' own k-means (its
-sub-sampling, seeding and iteration details) is not reproducible offline, so, as SURVEY.md §8c says,
-IVF parity is: (i) the scan is exact over the probed lists given this build's centroids and
+Build and search are hand-written HIP: assignment = ``amdrec_ivf_assign`` (fp32-MFMA GEMM with an arg-max epilogue),
+training = ``amdrec_ivf_kmeans_step`` x NITER (assignment + order-independent fixed-point centroid sums: training is
+bit-reproducible), and a search call launches only libamdrec kernels (no ATen op, no host synchronisation: it can be
+captured in a HIP graph).  What stays in torch is build-time data plumbing: drawing the training sample and the one
+stable sort that lays the corpus out list-contiguously after an ``add``.
+faiss' own k-means (its sub-sampling, seeding and iteration details) is not reproducible offline, so, as SURVEY.md
+section 8c says, IVF parity is: (i) the scan is exact over the probed lists given this build's centroids and
 assignments (tested against the oracle), (ii) recall@k against the Flat result is reported.
 Trainer: spherical Lloyd, max-inner-product assignment (the quantizer is IndexFlatIP), <= 256
 training points per centroid, 10 iterations, seed 1234 (faiss' documented defaults).
+Sharding: the centroids are SHARED by all ranks (``amdrec.sharded.share_ivf_centroids``); a rank
+files its own rows under them and holds its slice of every list, so the union of the ranks' scans is exactly the
+unsharded scan and the merged top-k is bit-identical to the unsharded IVF result.
 """
 from __future__ import annotations
 
@@ -31,11 +37,18 @@ def _normalize(x):
     return x / x.norm(dim=1, keepdim=True).clamp_min(1e-30)
 
 
-def _assign(x: torch.Tensor, cent: torch.Tensor, chunk: int = 1 << 16) -> torch.Tensor:
-    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
-    ct = cent.t().contiguous()
-    for s in range(0, x.shape[0], chunk):
-        out[s:s + chunk] = torch.argmax(x[s:s + chunk] @ ct, dim=1)
+def _assign(x: torch.Tensor, cent: torch.Tensor) -> torch.Tensor:
+    """amdrec_ivf_assign: arg max_c <x, c> per row (ties -> lower centroid)."""
+    lib = _lib.load()
+    x = x.contiguous()
+    n = x.shape[0]
+    out = torch.empty(n, dtype=torch.int64, device=x.device)
+    if n == 0:
+        return out
+    ws = _lib.WORKSPACE.get(n * 8 + 256, x.device)
+    _lib.check(lib.amdrec_ivf_assign(_lib.ptr(x), n, x.stride(0), x.shape[1], _lib.ptr(cent), cent.shape[0],
+                                     cent.stride(0), _lib.ptr(out), None, _lib.ptr(ws), ws.numel(),
+                                     _lib.stream_ptr(x.device)))
     return out
 
 
@@ -62,17 +75,15 @@ class IVFState:
             sel = torch.randperm(n, generator=g)[:MAX_POINTS_PER_CENTROID * nlist].to(x.device)
             x = x[sel]
             n = x.shape[0]
-        cent = x[torch.randperm(n, generator=g)[:nlist].to(x.device)].clone()
-        for _ in range(NITER):
-            a = _assign(x, cent)
-            order = torch.argsort(a, stable=True)
-            counts = torch.bincount(a, minlength=nlist)
-            try:                                                     # deterministic segmented sum
-                sums = torch.segment_reduce(x[order], "sum", lengths=counts, axis=0)
-            except Exception:                                        # pragma: no cover
-                sums = torch.zeros_like(cent).index_add_(0, a, x)
-            nonempty = counts > 0
-            cent = torch.where(nonempty[:, None], _normalize(sums), cent)
+        cent = x[torch.randperm(n, generator=g)[:nlist].to(x.device)].clone().contiguous()
+        x = x.contiguous()
+        lib = _lib.load()
+        nbytes = _lib.C.c_size_t(0)
+        _lib.check(lib.amdrec_ivf_kmeans_workspace(n, x.shape[1], nlist, _lib.C.byref(nbytes)))
+        ws = _lib.WORKSPACE.get(nbytes.value, x.device)
+        for _ in range(NITER):                                       # Lloyd iterations, all on libamdrec kernels
+            _lib.check(lib.amdrec_ivf_kmeans_step(_lib.ptr(x), n, x.stride(0), x.shape[1], _lib.ptr(cent), nlist,
+                                                  cent.stride(0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
         return cls(cent)
 
     def append(self, x_normalised: torch.Tensor, start: int):
@@ -109,31 +120,32 @@ class IVFState:
         cs = torch.empty((nq, nprobe), dtype=torch.float32, device=self.device)
         probes = torch.empty((nq, nprobe), dtype=torch.int64, device=self.device)
         flat_search(self.centroids, self.nlist, q, nprobe, cs, probes)
-        # 2. pool layout (tiny [nq, nprobe] integer plumbing)
-        plen = torch.where(probes >= 0, lens[probes.clamp_min(0)], torch.zeros_like(probes))
-        base = (torch.cumsum(plen, 1) - plen).contiguous()
-        n_pool = plen.sum(1).contiguous()
+        # 2. pool layout + (query, probe) pairs grouped by list: amdrec_ivf_group (kernels, no host sync)
+        base = torch.empty((nq, nprobe), dtype=torch.int64, device=self.device)
+        n_pool = torch.empty((nq,), dtype=torch.int64, device=self.device)
         pool_ld = max(1, nprobe * max_len)
         chunk = max(1, min(nq, 65535, POOL_BYTES // (pool_ld * 8)))
         grouped = nq >= GROUPED_MIN_QUERIES
         if grouped:                                   # one launch needs pairs/64 + nlist <= 65535 query tiles
             chunk = max(1, min(chunk, ((65535 - self.nlist) * QTILE) // nprobe))
-        ws = _lib.WORKSPACE.get(chunk * pool_ld * 8, self.device)
+        # one workspace: [candidate pool | grouping scratch | pair arrays and offsets]
+        pool_bytes = (chunk * pool_ld * 8 + 255) // 256 * 256
+        grp_bytes = ((self.nlist + 1) * 4 + 255) // 256 * 256 + (chunk * nprobe * 4 + 255) // 256 * 256
+        arr_bytes = 2 * chunk * nprobe * 8 + 2 * (self.nlist + 1) * 8
+        wsall = _lib.WORKSPACE.get(pool_bytes + grp_bytes + arr_bytes + 256, self.device)
+        ws = wsall[:pool_bytes]
+        grp = wsall[pool_bytes:pool_bytes + grp_bytes]
+        arr = wsall[pool_bytes + grp_bytes:pool_bytes + grp_bytes + arr_bytes].view(torch.int64)
+        pair_q, pair_p = arr[:chunk * nprobe], arr[chunk * nprobe:2 * chunk * nprobe]
+        goff = arr[2 * chunk * nprobe:2 * chunk * nprobe + self.nlist + 1]
+        qtp = arr[2 * chunk * nprobe + self.nlist + 1:]
         st = _lib.stream_ptr(self.device)
         for s in range(0, nq, chunk):
             m = min(chunk, nq - s)
+            _lib.check(lib.amdrec_ivf_group(_lib.ptr(probes[s:]), m, nprobe, self.nlist, _lib.ptr(lens), _lib.ptr(base[s:]),
+                                            _lib.ptr(n_pool[s:]), _lib.ptr(pair_q), _lib.ptr(pair_p), _lib.ptr(goff),
+                                            _lib.ptr(qtp), _lib.ptr(grp), grp.numel(), st))
             if grouped:
-                # sort this chunk's (query, probe) pairs by list: integer plumbing on [m * nprobe] elements
-                pl = probes[s:s + m].reshape(-1)
-                ls = torch.where(pl < 0, torch.full_like(pl, self.nlist), pl)
-                order = torch.argsort(ls, stable=True)
-                pair_q = (order // nprobe).contiguous()
-                pair_p = (order % nprobe).contiguous()
-                gcount = torch.bincount(ls, minlength=self.nlist + 1)[:self.nlist]
-                goff = torch.zeros(self.nlist + 1, dtype=torch.int64, device=self.device)
-                goff[1:] = torch.cumsum(gcount, 0)
-                qtp = torch.zeros(self.nlist + 1, dtype=torch.int64, device=self.device)
-                qtp[1:] = torch.cumsum((gcount + QTILE - 1) // QTILE, 0)
                 bound = (m * nprobe) // QTILE + self.nlist
                 _lib.check(lib.amdrec_ivf_scan_grouped(
                     _lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off), self.nlist, max_len,

@@ -71,6 +71,31 @@ class HipEngine:
         return self.rec._stage2(uc, un, cand_pos, top_k, False, ids_are_positions=True)
 
 
+def share_ivf_centroids(index, train_rows, rank: int, world: int, group=None, src: int = 0):
+    """One coarse quantizer for all ranks of a row-sharded IVF index: rank ``src`` trains k-means
+    on ``train_rows`` (its own shard's rows are an unbiased sample of a randomly sharded corpus) and broadcasts the
+    [nlist, d] centroids (4 MB at 4096 x 256: one small collective at BUILD time); every rank installs them and then
+    ``add``s its rows, which files them under the shared centroids - each rank ends up with its slice of EVERY list.
+    At query time all ranks compute identical probes (same centroids, same queries), scan their slices, and the usual
+    top-k exchange + merge returns exactly the unsharded IVF result."""
+    dev = index.device
+    if rank == src:
+        index.train(train_rows)
+        cent = index.centroids.clone()
+    else:
+        cent = torch.empty((index.nlist, index.dimension), dtype=torch.float32, device=dev)
+    if world > 1:
+        if cent.is_cuda and dist.get_backend(group) == "gloo":
+            h = cent.cpu()
+            dist.broadcast(h, src=src, group=group)
+            cent.copy_(h)
+        else:
+            dist.broadcast(cent, src=src, group=group)
+    if rank != src:
+        index.set_trained_centroids(cent)
+    return cent
+
+
 def all_gather_bytes(out: torch.Tensor, inp: torch.Tensor, group=None):
     """all_gather_into_tensor; device tensors under a gloo group (rehearsal of the multi-rank
     path on a box with fewer GPUs than ranks) are staged through the host."""

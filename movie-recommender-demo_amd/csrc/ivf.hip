@@ -198,9 +198,242 @@ __global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long lon
     write_result(buf, have, k, q, outD, outI, 0);
 }
 
+// ---- index BUILD: max-inner-product assignment and Lloyd iterations (faiss_retrieval.py:83-95, :118: IndexIVFFlat with an
+// IndexFlatIP quantizer trains k-means on first add and files every vector under the centroid of largest inner product) ----
+// Assignment = the GEMM mainloop (P = centroids: registers, Q = rows: lanes, fp32 MFMA: exact fma chains, so a row's
+// scores do not depend on tiling) with an arg-max epilogue: per row the best (score, centroid) key of the block's 256
+// centroids, folded across the centroid tiles with one 64-bit atomicMax per (wave, row).  key = (orderable score << 32) |
+// ~centroid: larger = better, equal scores -> LOWER centroid index (deterministic; NaN scores never win).
+struct EpiArgmax {
+    static constexpr const char* name = "ivf_assign";
+    static constexpr double out_bytes_per_elem = 0.0;
+    static constexpr size_t lds_bytes(int) { return 0; }
+    unsigned long long* keys;   // [rows], zero-initialised
+    long long rows;
+    int nlist;
+    template <class A>
+    __device__ void operator()(A& acc, float*) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = acc.p(i, r, lane);
+                    const float sc = acc.v[i][j][r];
+                    if (p < nlist && sc == sc) {
+                        const unsigned long long key = make_key(sc, (uint32_t)p);
+                        best = key > best ? key : best;
+                    }
+                }
+            const unsigned long long other = ((unsigned long long)__shfl_xor((unsigned)(best >> 32), 32, 64) << 32) |
+                                             (unsigned long long)__shfl_xor((unsigned)best, 32, 64);
+            best = other > best ? other : best;
+            const long long q = acc.q(j, lane);
+            if (lane < 32 && q < rows && best != 0ull) atomicMax(&keys[q], best);
+        }
+    }
+};
+
+__global__ void ivf_decode_assign_kernel(const unsigned long long* keys, long long rows, long long* assign, float* score) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const unsigned long long k = keys[i];
+    assign[i] = k ? (long long)key_pos(k) : 0ll;          // a row whose scores are all NaN goes to list 0
+    if (score) score[i] = k ? key_score(k) : -INFINITY;
+}
+
+// Centroid update, DETERMINISTIC: every coordinate is accumulated as a 64-bit fixed-point integer (x * 2^40, exact for
+// fp32 unit-vector coordinates down to 2^-16; integer addition is associative, so the sum does not depend on the order
+// the atomics land in - float atomics would make the trained centroids, and with them every IVF result, vary run to run).
+constexpr float IVF_FIX = 1099511627776.0f;      // 2^40; up to 2^22 unit rows per centroid before 2^62
+__global__ __launch_bounds__(256) void ivf_accumulate_kernel(const float* x, long long rows, long long ld, int d,
+                                                             const long long* assign, long long* sums, int* counts) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const long long a = assign[r];
+    for (int c = lane; c < d; c += 64) {
+        const float v = x[r * ld + c];
+        if (v == v) atomicAdd(reinterpret_cast<unsigned long long*>(&sums[a * d + c]), (unsigned long long)__float2ll_rn(v * IVF_FIX));
+    }
+    if (lane == 0) atomicAdd(&counts[a], 1);
+}
+// new centroid = sum / |sum| (spherical k-means: the quantizer compares inner products); empty clusters keep the old one
+__global__ __launch_bounds__(256) void ivf_finish_centroids_kernel(const long long* sums, const int* counts, int nlist, int d,
+                                                                   float* cent, long long ldc) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= nlist || counts[c] == 0) return;
+    double ss = 0.0;
+    for (int k = lane; k < d; k += 64) {
+        const double v = (double)sums[(long long)c * d + k];
+        ss += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (!(ss > 0.0)) return;
+    const double inv = 1.0 / sqrt(ss);
+    for (int k = lane; k < d; k += 64) cent[c * ldc + k] = (float)((double)sums[(long long)c * d + k] * inv);
+}
+
+// ---- query-time plumbing, sync-free (replaces torch argsort / bincount / cumsum per search call) ---------------------
+// pool layout of every query + rank of every (query, probe) pair inside its list's group (counting sort, pass 1)
+__global__ void ivf_group_count_kernel(const long long* probes, long long npairs, int nlist, int* cnt, int* rank) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    const long long l = probes[i];
+    rank[i] = atomicAdd(&cnt[(l < 0 || l >= nlist) ? nlist : (int)l], 1);
+}
+__global__ void ivf_pool_layout_kernel(const long long* probes, long long m, int nprobe, int nlist, const long long* list_len,
+                                       long long* base, long long* n_pool) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    long long run = 0;
+    for (int p = 0; p < nprobe; ++p) {
+        const long long l = probes[q * nprobe + p];
+        base[q * nprobe + p] = run;
+        run += (l >= 0 && l < nlist) ? list_len[l] : 0;
+    }
+    n_pool[q] = run;
+}
+// exclusive scans over the lists: group offsets and 64-query-tile offsets (one block)
+__global__ __launch_bounds__(1024) void ivf_group_prefix_kernel(const int* cnt, int nlist, long long* goff, long long* qtp) {
+    __shared__ long long sa[1024], sb[1024];
+    const int tid = threadIdx.x;
+    const int per = (nlist + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < nlist) ? lo + per : nlist;
+    long long a = 0, b = 0;
+    for (int l = lo; l < hi; ++l) { a += cnt[l]; b += (cnt[l] + 63) / 64; }
+    sa[tid] = a; sb[tid] = b;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                  // Hillis-Steele inclusive scan of the 1024 partials
+        const long long va = tid >= o ? sa[tid - o] : 0, vb = tid >= o ? sb[tid - o] : 0;
+        __syncthreads();
+        sa[tid] += va; sb[tid] += vb;
+        __syncthreads();
+    }
+    long long ra = sa[tid] - a, rb = sb[tid] - b;         // exclusive prefix of this thread's range
+    for (int l = lo; l < hi; ++l) {
+        goff[l] = ra; qtp[l] = rb;
+        ra += cnt[l]; rb += (cnt[l] + 63) / 64;
+    }
+    if (tid == 1023) { goff[nlist] = sa[1023]; qtp[nlist] = sb[1023]; }
+}
+__global__ void ivf_group_scatter_kernel(const long long* probes, long long npairs, int nprobe, int nlist, const int* rank,
+                                         const long long* goff, long long* pair_q, long long* pair_p) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    const long long l = probes[i];
+    if (l < 0 || l >= nlist) return;
+    const long long pos = goff[l] + rank[i];
+    pair_q[pos] = i / nprobe;
+    pair_p[pos] = i % nprobe;
+}
+
 }  // namespace amdrec
 
 using namespace amdrec;
+
+static int assign_impl(const float* x, long long rows, long long ld, int dim, const float* cent, int nlist, long long ldc,
+                       long long* assign, float* score, unsigned long long* keys, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(keys, 0, (size_t)rows * 8, st));
+    DenseRows lp{cent, nlist, (int)ldc, dim, 30, 1ll << 30};
+    DenseRows lq{x, rows, (int)ld, dim, 30, 1ll << 30};
+    EpiArgmax epi{keys, rows, nlist};
+    HIP_TRY((launch_gemm<Shape<2, 2, 4, 2>, true>(lp, lq, epi, dim, nlist, rows, st)));
+    hipLaunchKernelGGL(ivf_decode_assign_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, keys, rows, assign, score);
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
+
+static int assign_check(const float* x, int64_t rows, int64_t ld, int dim, const float* cent, int nlist, int64_t ldc) {
+    REQUIRE(dim >= 4 && dim % 4 == 0 && dim <= 2048, "dim=%d must be a multiple of 4 in [4,2048]", dim);
+    REQUIRE(nlist >= 1 && nlist <= (1 << 20), "nlist out of range");
+    REQUIRE(rows >= 0 && rows < (1ll << 31) - 1024, "rows out of range");
+    REQUIRE(ld >= dim && ld % 4 == 0 && ldc >= dim && ldc % 4 == 0 && ld < (1ll << 31) && ldc < (1ll << 31), "bad leading dimension");
+    REQUIRE(rows == 0 || (x && cent), "null pointer");
+    REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)cent % 16) == 0, "x / centroids must be 16-byte aligned");
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_ivf_assign(const float* x, int64_t rows, int64_t ld, int dim, const float* centroids, int nlist,
+                                 int64_t ld_centroids, int64_t* assign, float* best_score, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    int rc = assign_check(x, rows, ld, dim, centroids, nlist, ld_centroids);
+    if (rc) return rc;
+    if (rows == 0) return AMDREC_OK;
+    REQUIRE(assign != nullptr, "assign is null");
+    const size_t need = align_up((size_t)rows * 8, 256);
+    if (!workspace || workspace_bytes < need)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    return assign_impl(x, rows, ld, dim, centroids, nlist, ld_centroids, (long long*)assign, best_score,
+                       reinterpret_cast<unsigned long long*>(workspace), reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int amdrec_ivf_kmeans_workspace(int64_t rows, int dim, int nlist, size_t* bytes) {
+    REQUIRE(bytes != nullptr && rows >= 0 && dim >= 4 && nlist >= 1, "bad arguments");
+    *bytes = align_up((size_t)rows * 8, 256) + align_up((size_t)rows * 8, 256) + align_up((size_t)nlist * dim * 8, 256) +
+             align_up((size_t)nlist * 4, 256);
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_ivf_kmeans_step(const float* x, int64_t rows, int64_t ld, int dim, float* centroids, int nlist,
+                                      int64_t ld_centroids, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = assign_check(x, rows, ld, dim, centroids, nlist, ld_centroids);
+    if (rc) return rc;
+    if (rows == 0) return AMDREC_OK;
+    size_t need = 0;
+    amdrec_ivf_kmeans_workspace(rows, dim, nlist, &need);
+    if (!workspace || workspace_bytes < need)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws);
+    long long* assign = reinterpret_cast<long long*>(ws + align_up((size_t)rows * 8, 256));
+    long long* sums = reinterpret_cast<long long*>(ws + 2 * align_up((size_t)rows * 8, 256));
+    int* counts = reinterpret_cast<int*>(reinterpret_cast<char*>(sums) + align_up((size_t)nlist * dim * 8, 256));
+    rc = assign_impl(x, rows, ld, dim, centroids, nlist, ld_centroids, assign, nullptr, keys, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(sums, 0, align_up((size_t)nlist * dim * 8, 256) + (size_t)nlist * 4, st));
+    hipLaunchKernelGGL(ivf_accumulate_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, (long long)rows,
+                       (long long)ld, dim, assign, sums, counts);
+    hipLaunchKernelGGL(ivf_finish_centroids_kernel, dim3((unsigned)((nlist + 3) / 4)), dim3(256), 0, st, sums, counts, nlist,
+                       dim, centroids, (long long)ld_centroids);
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_ivf_group(const int64_t* probes, int64_t nq, int nprobe, int nlist, const int64_t* list_len,
+                                int64_t* pool_base, int64_t* pool_count, int64_t* pair_query, int64_t* pair_probe,
+                                int64_t* group_off, int64_t* qtile_prefix, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    REQUIRE(nprobe >= 1 && nlist >= 1 && nlist <= (1 << 20), "bad nlist/nprobe");
+    if (nq <= 0) return AMDREC_OK;
+    REQUIRE(nq * (int64_t)nprobe < (1ll << 31), "too many (query, probe) pairs for one call");
+    REQUIRE(probes && list_len && pool_base && pool_count && pair_query && pair_probe && group_off && qtile_prefix, "null pointer");
+    const long long npairs = nq * nprobe;
+    const size_t need = align_up((size_t)(nlist + 1) * 4, 256) + align_up((size_t)npairs * 4, 256);
+    if (!workspace || workspace_bytes < need)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int* cnt = reinterpret_cast<int*>(workspace);
+    int* rank = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + align_up((size_t)(nlist + 1) * 4, 256));
+    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)(nlist + 1) * 4, st));
+    hipLaunchKernelGGL(ivf_group_count_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
+                       (const long long*)probes, npairs, nlist, cnt, rank);
+    hipLaunchKernelGGL(ivf_pool_layout_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const long long*)probes,
+                       (long long)nq, nprobe, nlist, (const long long*)list_len, (long long*)pool_base, (long long*)pool_count);
+    hipLaunchKernelGGL(ivf_group_prefix_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, (long long*)group_off, (long long*)qtile_prefix);
+    hipLaunchKernelGGL(ivf_group_scatter_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
+                       (const long long*)probes, npairs, nprobe, nlist, rank, (const long long*)group_off,
+                       (long long*)pair_query, (long long*)pair_probe);
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
 
 extern "C" int amdrec_ivf_scan(const float* lists, int64_t ld, int dim, const int64_t* row_pos,
                                const int64_t* list_off, const float* queries, int64_t nq, int64_t ld_queries,
@@ -240,6 +473,7 @@ extern "C" int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, 
         attr_done.mark();
     }
     const unsigned gx = (unsigned)((max_list_rows + ShapeIvf::BQ - 1) / ShapeIvf::BQ);
+    ProfScope prof("ivf_scan_grouped_64x256", 0.0, 0.0, reinterpret_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(ivf_group_scan_kernel, dim3(gx, (unsigned)qtile_bound), dim3(ShapeIvf::NT), ShapeIvf::LDS_BYTES,
                        reinterpret_cast<hipStream_t>(stream), lists, (long long)ld, dim, (dim + BK - 1) / BK,
                        (const long long*)row_pos, (const long long*)list_off, queries, (long long)ld_queries,
@@ -255,6 +489,7 @@ extern "C" int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, con
     REQUIRE(k >= 1 && k <= AMDREC_MAX_K, "k=%d outside [1,%d]", k, AMDREC_MAX_K);
     if (nq <= 0) return AMDREC_OK;
     REQUIRE(pool_keys && pool_count && out_scores && out_pos, "null pointer");
+    ProfScope prof("ivf_select", 0.0, 0.0, reinterpret_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(ivf_select_kernel, dim3((unsigned)nq), dim3(512), 0, reinterpret_cast<hipStream_t>(stream),
                        (const unsigned long long*)pool_keys, (long long)pool_ld, (const long long*)pool_count, k,
                        out_scores, (long long*)out_pos);

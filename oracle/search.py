@@ -163,7 +163,9 @@ def ivf_search(xb, assign, cent, xq, k, nprobe, probes=None):
         rows = np.concatenate([lists[c] for c in probe[q] if c >= 0]) if nprobe else np.zeros(0, int)
         if len(rows) == 0:
             continue
-        s = (xb[rows] @ xq[q]).astype(np.float32)
+        # float64 dot rounded to fp32: a row's score must not depend on which other rows are scanned with it (a BLAS
+        # matvec blocks by matrix shape; the sharded-vs-unsharded tests compare score BITS)
+        s = (xb[rows].astype(np.float64) @ xq[q].astype(np.float64)).astype(np.float32)
         order = np.lexsort((rows, -s.astype(np.float64)))[:k]
         D[q, :len(order)] = s[order]
         I[q, :len(order)] = rows[order]

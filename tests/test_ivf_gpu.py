@@ -85,3 +85,91 @@ def test_ivf_defaults_underfill_and_save_load(tmp_path):
     ids2, D2 = idx2.search(xq, 500)
     assert np.array_equal(ids, ids2) and np.array_equal(D, D2)
     assert idx2.get_stats() == idx.get_stats()
+
+
+def test_assign_is_argmax_and_training_is_bit_reproducible():
+    """amdrec_ivf_assign == arg max_c <x, c> (ties -> lower centroid), one amdrec_ivf_kmeans_step == assign + mean +
+    renormalise computed in numpy float64, and two trainings of the same data give IDENTICAL centroids (the centroid
+    sums are order-independent fixed-point integer atomics)."""
+    from amdrec import _lib, ivf
+    rng = np.random.default_rng(7)
+    x = _clustered(40_000, 256, 30, 7)
+    cent = x[rng.choice(len(x), 200, replace=False)].copy()
+    cent[13] = cent[5]                                               # two identical centroids: exact ties
+    xd, cd = torch.from_numpy(x).cuda(), torch.from_numpy(cent).cuda()
+    got = ivf._assign(xd, cd).cpu().numpy()
+    sc = x.astype(np.float64) @ cent.astype(np.float64).T
+    ref = np.argmax(sc, axis=1)                                      # first maximum = lower index
+    bad = got != ref
+    # fp32 vs float64 may disagree only where the two best scores are within fp32 rounding of each other
+    assert bad.mean() < 1e-3 and (np.abs(sc[bad, got[bad]] - sc[bad, ref[bad]]) <= 2e-6).all()
+    assert not (got == 13).any()                                     # the duplicate never wins a tie against its lower twin
+    # one Lloyd step
+    lib = _lib.load()
+    c1 = cd.clone()
+    nbytes = _lib.C.c_size_t(0)
+    _lib.check(lib.amdrec_ivf_kmeans_workspace(len(x), 256, 200, _lib.C.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.amdrec_ivf_kmeans_step(_lib.ptr(xd), len(x), 256, 256, _lib.ptr(c1), 200, 256, _lib.ptr(ws), ws.numel(),
+                                          _lib.stream_ptr(xd.device)))
+    exp = cent.astype(np.float64).copy()
+    for c in range(200):
+        m = x[got == c]
+        if len(m):
+            s = m.astype(np.float64).sum(axis=0)
+            exp[c] = s / np.linalg.norm(s)
+    assert np.abs(c1.cpu().numpy() - exp).max() <= 2e-7
+    a = ivf.IVFState.train(xd, 128).centroids
+    b = ivf.IVFState.train(xd.clone(), 128).centroids
+    assert torch.equal(a, b)
+
+
+def test_two_shards_sharing_centroids_equal_the_unsharded_ivf_bit_for_bit():
+    """SURVEY.md section 8e for IVF: ranks share the trained centroids and hold their slice of every list; per-shard
+    searches merged by amdrec_topk_merge == the unsharded IVF search, exactly (positions and score bits)."""
+    from amdrec.index import FAISSIndex
+    from amdrec.sharded import HipEngine, packed_layout
+    n, nq, k, nlist, nprobe = 50_000, 40, 200, 128, 9
+    xb, xq = _clustered(n, 256, 50, 11), _clustered(nq, 256, 50, 12)
+    full = FAISSIndex(256, index_type="IVF", nlist=nlist, nprobe=nprobe)
+    full.add(xb)
+    q = torch.from_numpy(oracle.search.normalize_l2(xq)).cuda()
+    ref_pos, ref_sc = full.search_device(q, k, normalize=False, return_positions=True)
+    s_bytes, chunk = packed_layout(nq, k)
+    G = 2
+    gathered = torch.empty(chunk * G, dtype=torch.uint8, device="cuda")
+    cuts = [0, 21_337, n]                                              # uneven shards
+    for g in range(G):
+        sh = FAISSIndex(256, index_type="IVF", nlist=nlist, nprobe=nprobe)
+        sh.set_trained_centroids(full.centroids)
+        sh.add(xb[cuts[g]:cuts[g + 1]])
+        pos, sc = sh.search_device(q, k, normalize=False, return_positions=True, pos_offset=cuts[g])
+        c = gathered[g * chunk:(g + 1) * chunk]
+        c[:nq * k * 4].view(torch.float32).copy_(sc.reshape(-1))
+        c[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))
+    sc, pos = HipEngine(None, 0).merge(gathered, G, nq, k, 0, nq)
+    assert torch.equal(pos, ref_pos) and torch.equal(sc, ref_sc)
+    # and the unsharded result is the oracle's given the same centroids / probes
+    cent = full.centroids.cpu().numpy()
+    assign = full._ivf.assign.cpu().numpy()
+    rD, rI = oracle.search.ivf_search(oracle.search.normalize_l2(xb), assign, cent, q.cpu().numpy(), k, nprobe)
+    agree = np.mean([len(set(a) & set(b)) / k for a, b in zip(ref_pos.cpu().numpy(), rI)])
+    assert agree >= 0.98                                               # differences: coarse near-ties only
+
+
+def test_ivf_pipeline_captures_in_a_hip_graph():
+    """an IVF search used to call torch.bincount (a host sync) per query batch, which is illegal during
+    stream capture; the grouping is now kernels (amdrec_ivf_group).  Capture + replay == eager, for a batch on the
+    per-pair scan (B = 4) and one on the grouped MFMA scan (B = 32)."""
+    from tests.test_pipeline_gpu import _setup
+    rec, _, (user, ad, nnum) = _setup(20_000, 1.0 / 16, index_type="IVF")
+    assert rec.faiss_index.index_type == "IVF"
+    for B in (4, 32):
+        uc, un = synth.user_batch(user, nnum, B, seed=50 + B)
+        uc, un = torch.from_numpy(uc).cuda(), torch.from_numpy(un).cuda()
+        eager = rec.recommend_device(uc, un, 10, 200)
+        ids, sc = eager["ad_ids"].clone(), eager["scores"].clone()
+        g = rec.capture(B, 10, 200)
+        out = g(uc, un)
+        torch.cuda.synchronize()
+        assert torch.equal(out["ad_ids"], ids) and torch.equal(out["scores"], sc)

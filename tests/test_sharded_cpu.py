@@ -136,3 +136,82 @@ def test_user_slice_and_layout():
     assert [user_slice(4096, r, 8) for r in range(8)] == [(512 * r, 512) for r in range(8)]
     s, c = packed_layout(7, 5)
     assert s == 7 * 5 * 4 and c == 2 * s
+
+
+# ---- sharded IVF with SHARED centroids --------------------------------------------------------
+class _FakeIvfIndex:
+    """The attributes amdrec.sharded.share_ivf_centroids touches, with the oracle's k-means behind train()."""
+
+    def __init__(self, dim, nlist):
+        self.dimension, self.nlist, self.device = dim, nlist, torch.device("cpu")
+        self._cent = None
+
+    def train(self, rows):
+        self._cent = torch.from_numpy(oracle.search.kmeans_ip(oracle.search.normalize_l2(np.asarray(rows)), self.nlist))
+
+    @property
+    def centroids(self):
+        return self._cent
+
+    def set_trained_centroids(self, c):
+        self._cent = c.clone()
+
+
+class IvfOracleEngine(OracleEngine):
+    def __init__(self, *a, cent=None, nprobe=4, **k):
+        super().__init__(*a, **k)
+        self.cent, self.nprobe = cent, nprobe
+        self.assign = oracle.search.assign_ip(self.index.xb, cent)           # this rank's rows under the SHARED centroids
+
+    def local_search(self, uc, un, k):
+        emb = oracle.towers.user_tower(self.tt_sd, uc.numpy(), un.numpy())
+        q = oracle.search.normalize_l2(emb)
+        D, I = oracle.search.ivf_search(self.index.xb, self.assign, self.cent, q, k, self.nprobe)
+        return torch.from_numpy(D), torch.from_numpy(np.where(I >= 0, I + self.offset, -1))
+
+
+def _ivf_worker(rank, world, port, q):
+    from amdrec.sharded import share_ivf_centroids
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(8)
+        per = (N_ADS + world - 1) // world
+        lo, hi = rank * per, min(N_ADS, (rank + 1) * per)
+        idx = _FakeIvfIndex(256, 16)
+        cent = share_ivf_centroids(idx, corpus[lo:hi], rank, world)            # rank 0 trains, everyone installs
+        assert torch.equal(idx.centroids, cent)
+        eng = IvfOracleEngine(tt_sd, rk_sd, corpus[lo:hi], lo, ad_table, cent=cent.numpy(), nprobe=4)
+        sr = ShardedRecommender(None, rank, world, lo, engine=eng)
+        out = sr.recommend_device(torch.from_numpy(uc), torch.from_numpy(un), TOPK, K1)
+        q.put((rank, out["user_offset"], cent.numpy(), out["candidate_ids"].numpy(), out["candidate_scores"].numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_ivf_with_shared_centroids_equals_unsharded_ivf():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ivf_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][2], res[1][2])                                # one quantizer on both ranks
+    cent = res[0][2]
+    tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(8)
+    xb = oracle.search.normalize_l2(corpus)
+    emb = oracle.search.normalize_l2(oracle.towers.user_tower(tt_sd, uc, un))
+    rD, rI = oracle.search.ivf_search(xb, oracle.search.assign_ip(xb, cent), cent, emb, K1, 4)
+    for rank, q0, _, cand, cs in res:
+        for j in range(len(cand)):
+            # union of the ranks' slices of the probed lists == the unsharded lists: bit-identical result
+            assert np.array_equal(cand[j], rI[q0 + j]) and np.array_equal(cs[j], rD[q0 + j])
