@@ -33,6 +33,12 @@ def short(name):
         return f"{epi}_256x128_x6"
     if "scan_filter_kernel" in name:
         return "search_filter_stream128x512_bf16"
+    if "ranker_x3_kernel" in name:
+        return "ranker_rowowner_128_x3"
+    if "finalize_mixed_kernel" in name:
+        return "search_finalize_mixed"
+    if "sample_threshold_kernel" in name:
+        return "search_threshold"
     return name.split("(")[0].replace("amdrec::", "").replace("void ", "")[:60]
 
 
@@ -40,6 +46,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("-o", "--out", required=True)
+    ap.add_argument("--bench-json", help="the bench.py line of the profiled configuration: its `kernels` keys are stored as "
+                                         "`bench_tags`, and bench.py quotes this file only for runs with the same tag set")
     a = ap.parse_args()
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -68,9 +76,11 @@ def main():
                 e["wave_wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
         if e:
             out[k] = e
+    tags = sorted(json.load(open(a.bench_json))["kernels"]) if a.bench_json else []
     with open(a.out, "w") as f:
         json.dump({"note": "per-launch averages over all launches of the run; see tools/pmc_summary.py for units "
-                           "and the gfx950 FETCH_SIZE x2 correction", "kernels": out}, f, indent=1, sort_keys=True)
+                           "and the gfx950 FETCH_SIZE x2 correction", "bench_tags": tags, "kernels": out}, f, indent=1,
+                  sort_keys=True)
     for k, e in sorted(out.items()):
         print(k, {kk: (round(v, 3) if isinstance(v, float) and v < 10 else int(v)) for kk, v in e.items()})
 
