@@ -189,6 +189,10 @@ typedef struct {
     const void* stream;
     int64_t chunks;              /* stream length in 16 KB chunks */
     int64_t min_rows;
+    const float* params;         /* every bias / LayerNorm weight / head vector of the chain as one device blob (layout:
+                                  * csrc/ranker_x3.hip x3_param_floats; amdrec/weights.py pack_x3_params), copied into LDS
+                                  * once per workgroup */
+    int64_t n_params;            /* floats, padded to a multiple of 1024; must fit 44 KB of LDS */
     float sw_ov[AMDREC_MAX_LAYERS], sw_1[AMDREC_MAX_LAYERS], sw_2[AMDREC_MAX_LAYERS];
     float hn[AMDREC_MAX_LAYERS], hb[AMDREC_MAX_LAYERS];
     float sw_cross[AMDREC_MAX_LAYERS];

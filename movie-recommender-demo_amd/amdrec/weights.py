@@ -30,7 +30,7 @@ class EncoderLayer(C.Structure):
 
 
 class X3Weights(C.Structure):
-    _fields_ = [("stream", _FP), ("chunks", C.c_int64), ("min_rows", C.c_int64),
+    _fields_ = [("stream", _FP), ("chunks", C.c_int64), ("min_rows", C.c_int64), ("params", _FP), ("n_params", C.c_int64),
                 ("sw_ov", C.c_float * MAX_LAYERS), ("sw_1", C.c_float * MAX_LAYERS), ("sw_2", C.c_float * MAX_LAYERS),
                 ("hn", C.c_float * MAX_LAYERS), ("hb", C.c_float * MAX_LAYERS), ("sw_cross", C.c_float * MAX_LAYERS),
                 ("sw_h1", C.c_float), ("sw_h2", C.c_float), ("hn_head", C.c_float), ("hb_head", C.c_float)]
@@ -169,6 +169,27 @@ def pack_x3_stream(mats: Dict) -> Dict:
             "hb_head": float(np.abs(mats["hb1"]).max()), **sc}
 
 
+X3_PARAM_FLOATS = 11264     # LDS parameter area of the kernel (csrc/rowowner.hpp PARAM_FLOATS)
+
+
+def pack_x3_params(layers: List[Dict], cross_b: List, head_b1, heads: List[Dict]) -> np.ndarray:
+    """The parameter blob of the row-owner kernel (layout: csrc/ranker_x3.hip x3_param_floats): per encoder layer
+    [b_ov | gamma1 | beta1 | b_1 | b_2 | gamma2 | beta2], per cross layer its bias, heads [stacked b_1] then per task
+    [b_2 (64) | w_3 (64) | b_3 padded to 4]; float32, zero-padded to a multiple of 1024."""
+    parts = []
+    for L in layers:
+        parts += [L["b_ov"], L["g1"], L["be1"], L["b1"], L["b2"], L["g2"], L["be2"]]
+    parts += list(cross_b)
+    parts.append(head_b1)
+    for h in heads:
+        parts += [h["b2"], h["w3"], np.concatenate([np.asarray(h["b3"], dtype=np.float64).reshape(-1), np.zeros(3)])]
+    blob = np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1) for a in parts]).astype(np.float32)
+    n = (len(blob) + 1023) // 1024 * 1024
+    out = np.zeros(n, dtype=np.float32)
+    out[:len(blob)] = blob
+    return out
+
+
 def _pad_k(w64, mult=32):
     out_f, k = w64.shape
     ld = (k + mult - 1) // mult * mult
@@ -263,7 +284,9 @@ def x3_eligible(sd: Dict, fuse_attention: bool) -> bool:
         return False
     h1 = int(sd[f"prediction_heads.{tasks[0]}.0.weight"].shape[0])
     h2 = int(sd[f"prediction_heads.{tasks[0]}.3.weight"].shape[0])
-    return h1 % 32 == 0 and h2 == 64
+    dff = [int(sd[f"transformer_layers.{i}.feed_forward.fc1.weight"].shape[0]) for i in range(l)]
+    n_par = sum(6 * 256 + d for d in dff) + 256 * c + len(tasks) * (h1 + 132)
+    return h1 % 32 == 0 and h2 == 64 and (n_par + 1023) // 1024 * 1024 <= X3_PARAM_FLOATS
 
 
 def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int, device, ln_eps=1e-5,
@@ -374,6 +397,20 @@ def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int
         for t in tasks:
             mats["h2"].append(f32(_np64(sd[f"prediction_heads.{t}.3.weight"])))
         x = pack_x3_stream(mats)
+        lay = []
+        for li in range(p.n_layers):
+            pre = f"transformer_layers.{li}"
+            wo = _np64(sd[f"{pre}.self_attention.W_o.weight"])
+            lay.append({"b_ov": wo @ _np64(sd[f"{pre}.self_attention.W_v.bias"]) + _np64(sd[f"{pre}.self_attention.W_o.bias"]),
+                        "g1": _np64(sd[f"{pre}.norm1.weight"]), "be1": _np64(sd[f"{pre}.norm1.bias"]),
+                        "b1": _np64(sd[f"{pre}.feed_forward.fc1.bias"]), "b2": _np64(sd[f"{pre}.feed_forward.fc2.bias"]),
+                        "g2": _np64(sd[f"{pre}.norm2.weight"]), "be2": _np64(sd[f"{pre}.norm2.bias"])})
+        blob = pack_x3_params(lay, [_np64(sd[f"feature_interaction.cross_biases.{ci}"]) for ci in range(p.n_cross)], b1,
+                              [{"b2": _np64(sd[f"prediction_heads.{t}.3.bias"]), "w3": _np64(sd[f"prediction_heads.{t}.6.weight"]),
+                                "b3": _np64(sd[f"prediction_heads.{t}.6.bias"])} for t in tasks])
+        assert len(blob) <= X3_PARAM_FLOATS
+        p.x3.params = pk.ptr(blob)
+        p.x3.n_params = len(blob)
         p.x3.stream = pk.ptr(x["stream"].view(np.int16))
         p.x3.chunks = x["chunks"]
         p.x3.min_rows = int(x3_min_rows)

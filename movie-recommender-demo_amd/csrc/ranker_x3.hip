@@ -6,9 +6,18 @@
 
 using namespace amdrec;
 
+// Parameter blob layout (floats; amdrec/weights.py pack_x3_params writes exactly this): per encoder layer
+// [b_ov 256 | gamma1 256 | beta1 256 | b_1 d_ff | b_2 256 | gamma2 256 | beta2 256], per cross layer [bias 256], heads
+// [b_1 n_tasks*h1] then per task [b_2 64 | w_3 64 | b_3 4]; padded to a multiple of 1024.
+static long long x3_param_floats(const amdrec_ranker_params* p) {
+    const long long n = (long long)p->n_layers * (6 * 256 + p->d_ff) + 256ll * p->n_cross + (long long)p->n_tasks * (p->head_h1 + 132);
+    return (n + 1023) / 1024 * 1024;
+}
+
 // eligibility of the engine for these parameters (the reference architecture: d_model 256, 64-wide head layer 2)
 static bool x3_eligible(const amdrec_ranker_params* p) {
-    if (p->x3.stream == nullptr || p->x3.chunks <= 0) return false;
+    if (p->x3.stream == nullptr || p->x3.chunks <= 0 || p->x3.params == nullptr) return false;
+    if (x3_param_floats(p) > x3::PARAM_FLOATS) return false;      // the parameter blob must fit its LDS area
     if (p->d_model != 256 || p->d_ff % 32 != 0 || p->head_h1 % 32 != 0 || p->head_h2 != 64) return false;
     if (2 * p->n_layers + p->n_cross + 1 > x3::MAX_PHASES || p->n_tasks > 4) return false;
     for (int l = 0; l < p->n_layers; ++l)
@@ -19,24 +28,32 @@ static bool x3_eligible(const amdrec_ranker_params* p) {
 // n_phases < 0: the whole chain
 static int x3_build(const amdrec_ranker_params* p, int n_phases, x3::Program& G) {
     memset(&G, 0, sizeof(G));
-    int n = 0;
+    int n = 0, o = 0;                                               // o: running offset into the parameter blob (floats)
     for (int l = 0; l < p->n_layers; ++l) {
-        const amdrec_encoder_layer& L = p->layers[l];
         x3::Phase& A = G.ph[n++];
-        A.type = x3::PH_ATTN_LN; A.b1 = L.b_o; A.gamma = L.ln1_g; A.beta = L.ln1_b; A.sw1 = p->x3.sw_ov[l];
+        A.type = x3::PH_ATTN_LN; A.b1 = o; A.gamma = o + 256; A.beta = o + 512; A.sw1 = p->x3.sw_ov[l];
         A.sw2 = 1.f; A.ln_eps = p->ln_eps;
+        o += 768;
         x3::Phase& F = G.ph[n++];
-        F.type = x3::PH_FFN_LN; F.n_steps = p->d_ff / 32; F.b1 = L.b_1; F.b2 = L.b_2; F.gamma = L.ln2_g; F.beta = L.ln2_b;
+        F.type = x3::PH_FFN_LN; F.n_steps = p->d_ff / 32; F.b1 = o; F.b2 = o + p->d_ff; F.gamma = o + p->d_ff + 256;
+        F.beta = o + p->d_ff + 512;
         F.sw1 = p->x3.sw_1[l]; F.sw2 = p->x3.sw_2[l]; F.hn = p->x3.hn[l]; F.hb = p->x3.hb[l]; F.ln_eps = p->ln_eps;
+        o += p->d_ff + 768;
     }
     for (int c = 0; c < p->n_cross; ++c) {
         x3::Phase& C = G.ph[n++];
-        C.type = x3::PH_CROSS; C.b1 = p->cross_b[c]; C.sw1 = p->x3.sw_cross[c]; C.sw2 = 1.f;
+        C.type = x3::PH_CROSS; C.b1 = o; C.sw1 = p->x3.sw_cross[c]; C.sw2 = 1.f;
+        o += 256;
     }
     x3::Phase& H = G.ph[n++];
-    H.type = x3::PH_HEADS; H.n_steps = p->head_h1 / 32; H.n_tasks = p->n_tasks; H.b1 = p->head_b1;
+    H.type = x3::PH_HEADS; H.n_steps = p->head_h1 / 32; H.n_tasks = p->n_tasks; H.b1 = o;
     H.sw1 = p->x3.sw_h1; H.sw2 = p->x3.sw_h2; H.hn = p->x3.hn_head; H.hb = p->x3.hb_head;
-    for (int t = 0; t < p->n_tasks; ++t) { G.hb2[t] = p->head_b2[t]; G.hw3[t] = p->head_w3[t]; G.hb3[t] = p->head_b3[t]; }
+    o += p->n_tasks * p->head_h1;
+    for (int t = 0; t < p->n_tasks; ++t) { G.hb2[t] = o; G.hw3[t] = o + 64; G.hb3[t] = o + 128; o += 132; }
+    REQUIRE(p->x3.n_params == x3_param_floats(p), "x3: parameter blob has %lld floats, the architecture needs %lld",
+            (long long)p->x3.n_params, x3_param_floats(p));
+    G.params = p->x3.params;
+    G.n_params = (int)p->x3.n_params;
     // chunks consumed by a prefix of the chain (the ring only needs to know where the stream ends)
     const long long per_layer = 16 + 4ll * (p->d_ff / 32);          // W_ov: 16 chunks; FFN: 64 fragment sets per hidden tile
     const long long heads = (long long)p->n_tasks * (p->head_h1 / 32) * 40 / 16;
@@ -59,7 +76,7 @@ static int x3_launch(const x3::Program& G, const x3::Input& in, long long rows, 
     static PerDeviceOnce attr_done;
     if (attr_done.pending()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(x3::ranker_x3_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
         attr_done.mark();
     }
     const unsigned grid = (unsigned)((rows + x3::ROWS_PER_WG - 1) / x3::ROWS_PER_WG);
@@ -73,7 +90,7 @@ static int x3_launch(const x3::Program& G, const x3::Input& in, long long rows, 
             else w += (double)P.n_tasks * (256.0 * 32.0 * P.n_steps + 64.0 * 32.0 * P.n_steps + 64.0);
         }
         ProfScope prof("ranker_rowowner_128_x3", 2.0 * (double)rows * w, (double)rows * (1024.0 + 12.0), st);
-        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES, st, G, in, rows, scratch, x_out,
+        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES + x3::PARAM_FLOATS * 4, st, G, in, rows, scratch, x_out,
                            ld_xout, logits, ld_logits);
     }
     HIP_TRY(hipGetLastError());

@@ -51,9 +51,10 @@ constexpr int FRAG_BYTES = 1024;                 // one fragment set: 64 lanes x
 constexpr int CHUNK_FRAGS = 16;
 constexpr int CHUNK_BYTES = CHUNK_FRAGS * FRAG_BYTES;
 #ifndef AMDREC_X3_NBUF
-#define AMDREC_X3_NBUF 8
+#define AMDREC_X3_NBUF 7
 #endif
-constexpr int NBUF = AMDREC_X3_NBUF;             // ring chunks (8 x 16 KB = 128 KB)
+constexpr int NBUF = AMDREC_X3_NBUF;             // ring chunks (7 x 16 KB = 112 KB; 6, 8 and 9 measured the same)
+constexpr int PARAM_FLOATS = 11264;              // LDS parameter area behind the ring: 44 KB (the reference architecture needs 41.5)
 constexpr int RING_BYTES = NBUF * CHUNK_BYTES;
 constexpr int DEPTH = NBUF - 3;                  // chunks in flight beyond the certified one (NBUF >= DEPTH + 3)
 constexpr int ROWS_PER_WAVE = 32, WAVES = 4, ROWS_PER_WG = ROWS_PER_WAVE * WAVES;
@@ -66,10 +67,11 @@ struct Phase {
     int n_steps;            // FFN: d_ff / 32 hidden tiles; HEADS: head_h1 / 32 hidden tiles per task
     int n_tasks;            // HEADS
     int pad_;
-    const float* b1;        // ATTN/CROSS: bias [256]; FFN: b_1 [d_ff]; HEADS: stacked b_1 [n_tasks * head_h1]
-    const float* b2;        // FFN: b_2 [256]
-    const float* gamma;     // LayerNorm weight / bias [256] (ATTN, FFN)
-    const float* beta;
+    // offsets (in floats) into the parameter blob, which is DMA'd into LDS once per workgroup (see Program::params)
+    int b1;                 // ATTN/CROSS: bias [256]; FFN: b_1 [d_ff]; HEADS: stacked b_1 [n_tasks * head_h1]
+    int b2;                 // FFN: b_2 [256]
+    int gamma;              // LayerNorm weight / bias [256] (ATTN, FFN)
+    int beta;
     float sw1, sw2;         // power-of-two scales of the packed weight planes (W_ov / W_1 / W_c / head W_1; W_2 / head W_2)
     float hn, hb;           // FFN / HEADS hidden bound: |relu(w_j . x + b_j)| <= hn * (2^13 / row scale) + hb, with
                             // hn = 16 max_j ||w_j||_2 (||x||_2 <= 16 max|x| over 256 features), hb = max_j |b_j|
@@ -81,9 +83,16 @@ struct Program {
     int n_phases;
     int total_chunks;                   // length of the weight stream in 16 KB chunks
     const unsigned char* stream;        // packed fragment sets
-    const float* hb2[4];                // HEADS, per task: b_2 [64], w_3 [64], b_3 [1]
-    const float* hw3[4];
-    const float* hb3[4];
+    // All biases / LayerNorm weights / head vectors of the chain as ONE float blob (amdrec/weights.py pack_x3_params:
+    // per layer b_ov, gamma1, beta1, b_1, b_2, gamma2, beta2; per cross layer its bias; heads b_1, then per task b_2, w_3,
+    // b_3 padded to 4).  The kernel copies it into LDS behind the ring at start; a lane then reads the 4 parameters of
+    // its features with ONE ds_read_b128 (lanes of a half share the address: a broadcast) - scalar loads needed a select
+    // per element for the lane half and so many SGPRs that ~600 of them spilled at every phase transition.
+    const float* params;
+    int n_params;                       // floats, multiple of 1024 (padded), <= PARAM_FLOATS
+    int hb2[4];                         // HEADS, per task: offsets of b_2 [64], w_3 [64], b_3 [4]
+    int hw3[4];
+    int hb3[4];
     Phase ph[MAX_PHASES];
 };
 
@@ -100,14 +109,11 @@ struct Input {
     int rowdiv;
 };
 
-// ---- scalar (uniform-address) parameter loads: SMEM, counted by lgkmcnt, invisible to the ring's vmcnt ----------
-__device__ __forceinline__ f32x8 sload8(const float* p) {
-    return *reinterpret_cast<const __attribute__((address_space(4))) f32x8*>(reinterpret_cast<uintptr_t>(p));
-}
-// the 4 parameters of features f0 + 8 g + 4 h + {0..3} for this lane half: one 8-float scalar load, halves selected
-__device__ __forceinline__ f32x4 param4(const float* p, int f0, int g, int h) {
-    const f32x8 v = sload8(p + f0 + 8 * g);
-    return h ? f32x4{v[4], v[5], v[6], v[7]} : f32x4{v[0], v[1], v[2], v[3]};
+// ---- parameters: the 4 values of features f0 + 8 g + 4 h + {0..3} of array `off` = one ds_read_b128 from the LDS copy
+// of the blob (`pb` = LDS address of the blob + 16 h bytes, per lane; every lane of a half reads the same address)
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+__device__ __forceinline__ f32x4 param4(lds_cfloat* pb, int off, int f0, int g) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(pb + off + f0 + 8 * g);
 }
 
 // ---- the ring --------------------------------------------------------------------------------------------------
@@ -256,7 +262,7 @@ __device__ __forceinline__ void gemm256(Ring& ring, const f16x8 (&xh)[16], const
 }
 
 // ---- in-register LayerNorm over the 256 features of each row (transformer_ranker.py:149, :153; two-pass) -----------
-__device__ __forceinline__ void layer_norm(f32x16 (&y)[8], const float* gamma, const float* beta, float eps, int h) {
+__device__ __forceinline__ void layer_norm(f32x16 (&y)[8], lds_cfloat* pb, int gamma, int beta, float eps) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -278,22 +284,9 @@ __device__ __forceinline__ void layer_norm(f32x16 (&y)[8], const float* gamma, c
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 ga = param4(gamma, 32 * i, g, h), be = param4(beta, 32 * i, g, h);
+            const f32x4 ga = param4(pb, gamma, 32 * i, g), be = param4(pb, beta, 32 * i, g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[i][4 * g + e] = (y[i][4 * g + e] - mean) * rstd * ga[e] + be[e];
-        }
-}
-
-// acc[i][r] = (x[i][r] * use_x + bias[feature]) * scale        (the accumulator's initial value: bias and residual)
-template <bool WITH_X>
-__device__ __forceinline__ void init_acc(f32x16 (&acc)[8], const f32x16 (&x)[8], const float* bias, float scale, int h) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = param4(bias, 32 * i, g, h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][4 * g + e] = ((WITH_X ? x[i][4 * g + e] : 0.f) + b[e]) * scale;
         }
 }
 
@@ -301,7 +294,7 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[8], const f32x16 (&x)[8],
 // so the three register sets (x, planes, accumulators: 128 each) are never all live (measured: the unfused order spilled
 // ~150 VGPRs per phase transition into scratch, 3 GB of HBM traffic per launch).  acc[i] = (x[i] * WITH_X + bias) * scale.
 template <bool WITH_X>
-__device__ __forceinline__ void prepare(const f32x16 (&x)[8], float s, const float* bias, float scale, int h,
+__device__ __forceinline__ void prepare(const f32x16 (&x)[8], float s, lds_cfloat* pb, int bias, float scale,
                                         f16x8 (&xh)[16], f16x8 (&xl)[16], f32x16 (&acc)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -309,7 +302,7 @@ __device__ __forceinline__ void prepare(const f32x16 (&x)[8], float s, const flo
         for (int sp = 0; sp < 2; ++sp) split8(x[i], 8 * sp, s, xh[2 * i + sp], xl[2 * i + sp]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 b = param4(bias, 32 * i, g, h);
+            const f32x4 b = param4(pb, bias, 32 * i, g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][4 * g + e] = ((WITH_X ? x[i][4 * g + e] : 0.f) + b[e]) * scale;
         }
@@ -317,19 +310,19 @@ __device__ __forceinline__ void prepare(const f32x16 (&x)[8], float s, const flo
 }
 
 // ---- x = LN(x + W x + b) ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void phase_attn_ln(Ring& ring, const Phase& P, f32x16 (&x)[8], int h) {
+__device__ __forceinline__ void phase_attn_ln(Ring& ring, const Phase& P, f32x16 (&x)[8], lds_cfloat* pb) {
     float s, inv;
     row_scale(x, s, inv);
     f16x8 xh[16], xl[16];
     f32x16 acc[8];
-    prepare<true>(x, s, P.b1, s * P.sw1, h, xh, xl, acc);
+    prepare<true>(x, s, pb, P.b1, s * P.sw1, xh, xl, acc);
     gemm256(ring, xh, xl, acc);
     const float un = inv / P.sw1;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[i][r] = acc[i][r] * un;
-    layer_norm(x, P.gamma, P.beta, P.ln_eps, h);
+    layer_norm(x, pb, P.gamma, P.beta, P.ln_eps);
 }
 
 // ---- hidden tile -> planes: H = relu(acc1) * c (c = hidden scale / (2^sw1 * row scale)), clamped below the fp16 maximum
@@ -344,10 +337,10 @@ __device__ __forceinline__ void hidden_planes(const f32x16& a1, float c, f16x8 (
     split8(t, 0, 1.0f, hh[0], hl[0]);
     split8(t, 8, 1.0f, hh[1], hl[1]);
 }
-__device__ __forceinline__ void init_tile(f32x16& a, const float* bias, int f0, float scale, int h) {
+__device__ __forceinline__ void init_tile(f32x16& a, lds_cfloat* pb, int bias, int f0, float scale) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 b = param4(bias, f0, g, h);
+        const f32x4 b = param4(pb, bias, f0, g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[4 * g + e] = b[e] * scale;
     }
@@ -386,22 +379,22 @@ __device__ __forceinline__ void ffn_step(Ring& ring, const f16x8 (&xh)[16], cons
 }
 
 // ---- x = LN(x + W_2 relu(W_1 x + b_1) + b_2) -----------------------------------------------------------------------
-__device__ __forceinline__ void phase_ffn_ln(Ring& ring, const Phase& P, f32x16 (&x)[8], int h) {
+__device__ __forceinline__ void phase_ffn_ln(Ring& ring, const Phase& P, f32x16 (&x)[8], lds_cfloat* pb) {
     float s, inv;
     row_scale(x, s, inv);
     f16x8 xh[16], xl[16];
     const float sh = hidden_scale(fmaf(P.hn * 8192.0f, inv, P.hb));   // max|x| < 2^13 / s
     f32x16 acc2[8];
-    prepare<true>(x, s, P.b2, P.sw2 * sh, h, xh, xl, acc2);  // planes; residual + b_2 in stage 2's scaled domain
+    prepare<true>(x, s, pb, P.b2, P.sw2 * sh, xh, xl, acc2);  // planes; residual + b_2 in stage 2's scaled domain
     const float b1s = s * P.sw1;                              // stage 1 accumulates (W_1 2^sw1)(x s)
     const float c1 = sh * inv / P.sw1;                        // acc1 -> H sh
     f32x16 acc1;
     f16x8 hh[2], hl[2];
-    init_tile(acc1, P.b1, 0, b1s, h);
+    init_tile(acc1, pb, P.b1, 0, b1s);
     ffn_step<true, false>(ring, xh, xl, acc1, acc2, hh, hl);
     for (int t = 1; t < P.n_steps; ++t) {
         hidden_planes(acc1, c1, hh, hl);
-        init_tile(acc1, P.b1, 32 * t, b1s, h);
+        init_tile(acc1, pb, P.b1, 32 * t, b1s);
         ffn_step<true, true>(ring, xh, xl, acc1, acc2, hh, hl);
     }
     hidden_planes(acc1, c1, hh, hl);
@@ -411,7 +404,7 @@ __device__ __forceinline__ void phase_ffn_ln(Ring& ring, const Phase& P, f32x16 
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[i][r] = acc2[i][r] * un;
-    layer_norm(x, P.gamma, P.beta, P.ln_eps, h);
+    layer_norm(x, pb, P.gamma, P.beta, P.ln_eps);
 }
 
 // ---- row I/O in accumulator layout: lane (q, h) moves the 16-byte groups [32 i + 8 g + 4 h, +4) of row q -------------
@@ -445,12 +438,13 @@ __device__ __forceinline__ void store_rows(const f32x16 (&x)[8], float* row_ptr,
 }
 
 // ---- xl = x0 * (W xl + b) + xl   (FeatureInteractionLayer :199-202); x0 is re-read from `x0_row` (scratch, L2) -------
-__device__ __forceinline__ void phase_cross(Ring& ring, const Phase& P, f32x16 (&xl_)[8], const float* x0_row, int h) {
+__device__ __forceinline__ void phase_cross(Ring& ring, const Phase& P, f32x16 (&xl_)[8], const float* x0_row, int h,
+                                            lds_cfloat* pb) {
     float s, inv;
     row_scale(xl_, s, inv);
     f16x8 xh[16], xl[16];
     f32x16 acc[8];
-    prepare<false>(xl_, s, P.b1, s * P.sw1, h, xh, xl, acc);
+    prepare<false>(xl_, s, pb, P.b1, s * P.sw1, xh, xl, acc);
     gemm256(ring, xh, xl, acc);
     const float un = inv / P.sw1;
 #pragma unroll
@@ -467,7 +461,7 @@ __device__ __forceinline__ void phase_cross(Ring& ring, const Phase& P, f32x16 (
 // stream per task: for t in hidden tiles: stage 1 {A1_h(t, u), A1_l(t, u)} u = 0..15 (32 sets), then stage 2
 // {A2_h(i, s), A2_l(i, s)} for s = 0, 1, i = 0, 1 (8 sets): 40 sets per hidden tile, 8 tiles = 320 sets = 20 chunks.
 __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const Phase& P, const f32x16 (&x)[8], float* out,
-                                            long long ld_out, long long row, bool row_ok, int h) {
+                                            long long ld_out, long long row, bool row_ok, int h, lds_cfloat* pb) {
     float s, inv;
     row_scale(x, s, inv);
     f16x8 xh[16], xl[16];
@@ -477,10 +471,10 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
     for (int task = 0; task < P.n_tasks; ++task) {
         f32x16 acc2[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) init_tile(acc2[i], G.hb2[task], 32 * i, P.sw2 * sh, h);
+        for (int i = 0; i < 2; ++i) init_tile(acc2[i], pb, G.hb2[task], 32 * i, P.sw2 * sh);
         for (int t = 0; t < P.n_steps; ++t) {
             f32x16 acc1;
-            init_tile(acc1, P.b1 + task * P.n_steps * 32, 32 * t, b1s, h);
+            init_tile(acc1, pb, P.b1 + task * P.n_steps * 32, 32 * t, b1s);
             f16x8 cur[2], nxt[2];
             ring.read<2>(cur);
 #pragma unroll
@@ -504,12 +498,12 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 w = param4(G.hw3[task], 32 * i, g, h);
+                const f32x4 w = param4(pb, G.hw3[task], 32 * i, g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dot += fmaxf(acc2[i][4 * g + e] * un2, 0.f) * w[e];
             }
         dot += __shfl_xor(dot, 32, 64);
-        if (h == 0 && row_ok) out[(long long)task * ld_out + row] = dot + G.hb3[task][0];
+        if (h == 0 && row_ok) out[(long long)task * ld_out + row] = dot + pb[G.hb3[task] - 4 * h];   // b_3 (h == 0 here)
     }
 }
 
@@ -524,6 +518,15 @@ __global__ __launch_bounds__(256, 1) void ranker_x3_kernel(Program G, Input in, 
     const long long row = (long long)blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE + q;
     const bool row_ok = row < rows;
     const long long rowc = row_ok ? row : rows - 1;                 // clamped: branch-free loads, stores are guarded
+
+    // parameter blob -> LDS behind the ring (plain LDS-DMA, 4 KB per pass of the workgroup), visible after the ring's first barrier
+    lds_byte* pbase = (lds_byte*)smem + RING_BYTES;
+    for (int o = 0; o < G.n_params * 4; o += 4096)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(
+                                             reinterpret_cast<const unsigned char*>(G.params) + o + tid * 16),
+                                         (__attribute__((address_space(3))) void*)(pbase + o + wave * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_cfloat* pb = reinterpret_cast<lds_cfloat*>(pbase) + 4 * h;   // lane half h reads features + 4 h
 
     Ring ring;
     ring.start(G.stream, G.total_chunks, (lds_byte*)smem, wave, lane);
@@ -544,17 +547,17 @@ __global__ __launch_bounds__(256, 1) void ranker_x3_kernel(Program G, Input in, 
         const Phase& P = G.ph[p];
         const int type = __builtin_amdgcn_readfirstlane(P.type);
         if (type == PH_ATTN_LN) {
-            phase_attn_ln(ring, P, x, h);
+            phase_attn_ln(ring, P, x, pb);
         } else if (type == PH_FFN_LN) {
-            phase_ffn_ln(ring, P, x, h);
+            phase_ffn_ln(ring, P, x, pb);
         } else if (type == PH_CROSS) {
             if (!x0_saved) {                                        // x0 = the encoder output, kept for all cross layers
                 store_rows(x, x0_row, h);
                 x0_saved = true;
             }
-            phase_cross(ring, P, x, x0_row, h);
+            phase_cross(ring, P, x, x0_row, h, pb);
         } else {
-            phase_heads(ring, G, P, x, logits, ld_logits, row, row_ok, h);
+            phase_heads(ring, G, P, x, logits, ld_logits, row, row_ok, h, pb);
         }
     }
     if (x_out != nullptr && row_ok) store_rows(x, x_out + row * ld_xout, h);

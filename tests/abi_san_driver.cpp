@@ -97,6 +97,11 @@ int main() {
     // fp16x3 engine: eligibility and stream-length checks are host logic
     EXPECT(amdrec_ranker_x3_prefix(&rp, fp, 256, 10, -1, fp, 256, fp, 10, fake, 4096, nullptr) < 0);               // no stream
     rp.x3.stream = fake; rp.x3.chunks = 5;
+    EXPECT(amdrec_ranker_x3_prefix(&rp, fp, 256, 10, -1, fp, 256, fp, 10, fake, 4096, nullptr) < 0);               // no parameter blob
+    rp.x3.params = fp; rp.x3.n_params = 7;
+    EXPECT(amdrec_ranker_x3_prefix(&rp, fp, 256, 10, -1, fp, 256, fp, 10, fake, 4096, nullptr) < 0 &&
+           strstr(amdrec_last_error(), "parameter blob") != nullptr);                                            // wrong blob size
+    rp.x3.n_params = 10240;                                       // 3 * (1536 + 1024) + 3 * 256 + 3 * (256 + 132) = 9612 -> padded
     EXPECT(amdrec_ranker_x3_prefix(&rp, fp, 256, 10, -1, fp, 256, fp, 10, fake, 4096, nullptr) < 0 &&
            strstr(amdrec_last_error(), "chunks") != nullptr);                                                    // wrong stream length
     rp.x3.chunks = 3 * (16 + 128) + 48 + 60;

@@ -27,8 +27,8 @@ int main(int argc, char** argv) {
     for (auto& v : X) v = (float)(rand() % 2001 - 1000) / 500.f;
     CK(hipMalloc(&dX, X.size() * 4));
     CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
-    std::vector<float> par(4096, 0.01f);
-    for (int i = 2048; i < 4096; ++i) par[i] = 1.0f;     // gamma
+    std::vector<float> par(x3::PARAM_FLOATS, 0.01f);     // the blob: every parameter 0.01 except "gamma" = 1 at 2048..4095
+    for (int i = 2048; i < 4096; ++i) par[i] = 1.0f;
     CK(hipMalloc(&dpar, par.size() * 4));
     CK(hipMemcpy(dpar, par.data(), par.size() * 4, hipMemcpyHostToDevice));
     const long long prow = (rows + 127) / 128 * 128;
@@ -39,29 +39,30 @@ int main(int argc, char** argv) {
     const float sw = 65536.f * 64.f;     // packed weights ~2^10 -> real ~2^-12 .. 2^-5
     for (int l = 0; l < L; ++l) {
         x3::Phase& A = G.ph[n++];
-        A.type = x3::PH_ATTN_LN; A.b1 = dpar; A.gamma = dpar + 2048; A.beta = dpar; A.sw1 = sw; A.sw2 = 1; A.ln_eps = 1e-5f;
+        A.type = x3::PH_ATTN_LN; A.b1 = 0; A.gamma = 2048; A.beta = 0; A.sw1 = sw; A.sw2 = 1; A.ln_eps = 1e-5f;
         x3::Phase& F = G.ph[n++];
-        F.type = x3::PH_FFN_LN; F.n_steps = dff / 32; F.b1 = dpar; F.b2 = dpar; F.gamma = dpar + 2048; F.beta = dpar;
+        F.type = x3::PH_FFN_LN; F.n_steps = dff / 32; F.b1 = 0; F.b2 = 0; F.gamma = 2048; F.beta = 0;
         F.sw1 = sw; F.sw2 = sw; F.hn = 16.f * 0.5f; F.hb = 0.01f; F.ln_eps = 1e-5f;
     }
-    for (int c = 0; c < C; ++c) { x3::Phase& P = G.ph[n++]; P.type = x3::PH_CROSS; P.b1 = dpar; P.sw1 = sw; P.sw2 = 1; }
+    for (int c = 0; c < C; ++c) { x3::Phase& P = G.ph[n++]; P.type = x3::PH_CROSS; P.b1 = 0; P.sw1 = sw; P.sw2 = 1; }
     x3::Phase& H = G.ph[n++];
-    H.type = x3::PH_HEADS; H.n_steps = h1 / 32; H.n_tasks = T; H.b1 = dpar; H.sw1 = sw; H.sw2 = sw; H.hn = 8.f; H.hb = 0.01f;
-    for (int t = 0; t < T; ++t) { G.hb2[t] = dpar; G.hw3[t] = dpar; G.hb3[t] = dpar; }
+    H.type = x3::PH_HEADS; H.n_steps = h1 / 32; H.n_tasks = T; H.b1 = 0; H.sw1 = sw; H.sw2 = sw; H.hn = 8.f; H.hb = 0.01f;
+    for (int t = 0; t < T; ++t) { G.hb2[t] = 0; G.hw3[t] = 64; G.hb3[t] = 128; }
+    G.params = dpar; G.n_params = x3::PARAM_FLOATS;
     G.n_phases = n; G.total_chunks = (int)chunks; G.stream = (const unsigned char*)dstream;
     x3::Input in{};
     in.X = dX; in.ldx = 256;
-    CK(hipFuncSetAttribute((const void*)x3::ranker_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES));
+    CK(hipFuncSetAttribute((const void*)x3::ranker_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
     const unsigned grid = (unsigned)((rows + 127) / 128);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
+        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES + x3::PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
     CK(hipDeviceSynchronize());
     const int reps = 10;
     CK(hipEventRecord(e0));
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
+        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES + x3::PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms = 0;
