@@ -193,6 +193,8 @@ typedef struct {
                                   * csrc/ranker_x3.hip x3_param_floats; amdrec/weights.py pack_x3_params), copied into LDS
                                   * once per workgroup */
     int64_t n_params;            /* floats, padded to a multiple of 1024; must fit 44 KB of LDS */
+    int64_t variant;             /* 32: rowowner.hpp (32 rows per wave, one wave per SIMD); 16: rowowner16.hpp (16 rows per
+                                  * wave, two waves per SIMD); the stream is packed for exactly one of them */
     float sw_ov[AMDREC_MAX_LAYERS], sw_1[AMDREC_MAX_LAYERS], sw_2[AMDREC_MAX_LAYERS];
     float hn[AMDREC_MAX_LAYERS], hb[AMDREC_MAX_LAYERS];
     float sw_cross[AMDREC_MAX_LAYERS];

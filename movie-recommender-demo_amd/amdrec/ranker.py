@@ -89,6 +89,7 @@ class TransformerRanker(nn.Module):
         #  "fp32"   fp32 MFMA everywhere
         self.gemm_engine = "f16x3"
         self.x3_min_rows = self.SMALL_ROWS + 1       # tests set 1 to drive small batches through the row-owner kernel
+        self.x3_variant = 16                          # 16: rowowner16.hpp (two waves per SIMD, default: 15 % faster); 32: rowowner.hpp
 
     ENGINES = ("f16x3", "bf16x6", "fp32")
     SMALL_ROWS = 8192       # passes of at most this many rows run the fp32-MFMA small shapes (csrc/layers.hip)
@@ -149,7 +150,7 @@ class TransformerRanker(nn.Module):
     def _pack(self, device):
         if self.gemm_engine not in self.ENGINES:
             raise ValueError(f"gemm_engine must be one of {self.ENGINES}")
-        key = (str(device), self.fuse_attention, self.gemm_engine, int(self.x3_min_rows),
+        key = (str(device), self.fuse_attention, self.gemm_engine, int(self.x3_min_rows), int(self.x3_variant),
                tuple(p._version for p in self.parameters()))
         if self._packed is None or self._packed[0] != key:
             sd = self.state_dict()
@@ -158,7 +159,7 @@ class TransformerRanker(nn.Module):
                                                       self._n_num, device, fuse_attention=self.fuse_attention,
                                                       x6=self.gemm_engine == "bf16x6" or
                                                       (self.gemm_engine == "f16x3" and not x3),
-                                                      x3=x3, x3_min_rows=self.x3_min_rows)
+                                                      x3=x3, x3_min_rows=self.x3_min_rows, x3_variant=self.x3_variant)
             self._packed = (key, params, keep, tasks)
         return self._packed[1], self._packed[3]
 

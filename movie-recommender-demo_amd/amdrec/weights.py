@@ -31,6 +31,7 @@ class EncoderLayer(C.Structure):
 
 class X3Weights(C.Structure):
     _fields_ = [("stream", _FP), ("chunks", C.c_int64), ("min_rows", C.c_int64), ("params", _FP), ("n_params", C.c_int64),
+                ("variant", C.c_int64),
                 ("sw_ov", C.c_float * MAX_LAYERS), ("sw_1", C.c_float * MAX_LAYERS), ("sw_2", C.c_float * MAX_LAYERS),
                 ("hn", C.c_float * MAX_LAYERS), ("hb", C.c_float * MAX_LAYERS), ("sw_cross", C.c_float * MAX_LAYERS),
                 ("sw_h1", C.c_float), ("sw_h2", C.c_float), ("hn_head", C.c_float), ("hb_head", C.c_float)]
@@ -138,30 +139,88 @@ def x3_stream_heads(f1: np.ndarray, f2s: List[np.ndarray], tiles_per_task: int) 
     return np.stack(out)
 
 
-def pack_x3_stream(mats: Dict) -> Dict:
+# ---- 16-rows-per-wave variant (csrc/rowowner16.hpp): 16-feature output tiles, 32-wide k-steps ------------------------
+# k position i = 8 g + j of a 32-wide k-step holds feature offset 16 (j >> 2) + 4 g + (j & 3)
+_X3B_KSRC = np.array([16 * ((i & 7) >> 2) + 4 * (i >> 3) + (i & 3) for i in range(32)])
+
+
+def x3b_frags(w64: np.ndarray, scale: float) -> np.ndarray:
+    """[N][K] (N % 16 == 0, K % 32 == 0) -> uint16 [N/16][K/32][2 planes][64 lanes][8]: A fragments of
+    v_mfma_f32_16x16x32_f16 (lane = p + 16 g holds k positions 8 g .. 8 g + 7 of row p) with the 16-row kernel's k permutation."""
+    n, k = w64.shape
+    assert n % 16 == 0 and k % 32 == 0
+    ws = (np.asarray(w64, dtype=np.float64) * scale).astype(np.float32)
+    h = ws.astype(np.float16)
+    assert np.isfinite(h).all(), "x3 weight plane overflowed fp16"
+    l = (ws - h.astype(np.float32)).astype(np.float16)
+    planes = np.stack([h, l]).view(np.uint16)                                  # [2][N][K]
+    planes = planes.reshape(2, n, k // 32, 32)[:, :, :, _X3B_KSRC]             # position i <- source k offset
+    planes = planes.reshape(2, n // 16, 16, k // 32, 4, 8)                     # plane, tile, p, ks, g, j
+    return np.ascontiguousarray(planes.transpose(1, 3, 0, 4, 2, 5)).reshape(n // 16, k // 32, 2, 64, 8)
+
+
+def _pair(f, t0, ks):
+    return [f[t0, ks, 0], f[t0, ks, 1], f[t0 + 1, ks, 0], f[t0 + 1, ks, 1]]
+
+
+def x3b_stream_gemm256(fr):
+    out = []
+    for ks in range(fr.shape[1]):
+        for tp in range(fr.shape[0] // 2):
+            out += _pair(fr, 2 * tp, ks)
+    return np.stack(out)
+
+
+def x3b_stream_ffn(f1, f2):
+    T = f1.shape[0] // 2                     # hidden tiles of 32
+    out = []
+    for t in range(T + 1):
+        for u in range(8):
+            if t < T:
+                out += _pair(f1, 2 * t, u)
+            if t >= 1:
+                out += _pair(f2, 2 * u, t - 1)
+    return np.stack(out)
+
+
+def x3b_stream_heads(f1, f2s, tiles_per_task):
+    out = []
+    for task, f2 in enumerate(f2s):
+        for t in range(tiles_per_task):
+            for u in range(8):
+                out += _pair(f1, 2 * (task * tiles_per_task + t), u)
+            for pr in range(2):
+                out += _pair(f2, 2 * pr, t)
+    return np.stack(out)
+
+
+def pack_x3_stream(mats: Dict, variant: int = 32) -> Dict:
     """mats: float64 matrices of the chain {"ov": [L x [256][256]], "w1": [L x [d_ff][256]], "b1": [L x [d_ff]], "w2":
     [L x [256][d_ff]], "cross": [C x [256][256] (already [out][in])], "h1": [T*h1][256], "hb1": [T*h1], "h2": [T x
     [64][h1]]} -> {"stream": uint16 [n_frag][64][8], "chunks", scales and hidden bounds} for amdrec_x3_weights."""
+    assert variant in (16, 32)
+    frags, s_gemm, s_ffn, s_heads = ((x3_frags, x3_stream_gemm256, x3_stream_ffn, x3_stream_heads) if variant == 32 else
+                                     (x3b_frags, x3b_stream_gemm256, x3b_stream_ffn, x3b_stream_heads))
     parts = []
     sc = {"sw_ov": [], "sw_1": [], "sw_2": [], "hn": [], "hb": [], "sw_cross": []}
     for l in range(len(mats["ov"])):
         s_ov = x3_pow2_scale(np.abs(mats["ov"][l]).max())
-        parts.append(x3_stream_gemm256(x3_frags(mats["ov"][l], s_ov)))
+        parts.append(s_gemm(frags(mats["ov"][l], s_ov)))
         s1, s2 = x3_pow2_scale(np.abs(mats["w1"][l]).max()), x3_pow2_scale(np.abs(mats["w2"][l]).max())
-        parts.append(x3_stream_ffn(x3_frags(mats["w1"][l], s1), x3_frags(mats["w2"][l], s2)))
+        parts.append(s_ffn(frags(mats["w1"][l], s1), frags(mats["w2"][l], s2)))
         sc["sw_ov"].append(s_ov); sc["sw_1"].append(s1); sc["sw_2"].append(s2)
         # |relu(w_j . x + b_j)| <= ||w_j||_2 ||x||_2 + |b_j| <= (16 max_j ||w_j||_2) max|x| + max_j |b_j|
         sc["hn"].append(float(16.0 * np.linalg.norm(mats["w1"][l], axis=1).max() * (1 + 1e-6)))
         sc["hb"].append(float(np.abs(mats["b1"][l]).max()))
     for w in mats["cross"]:
         s = x3_pow2_scale(np.abs(w).max())
-        parts.append(x3_stream_gemm256(x3_frags(w, s)))
+        parts.append(s_gemm(frags(w, s)))
         sc["sw_cross"].append(s)
     sh1 = x3_pow2_scale(np.abs(mats["h1"]).max())
     sh2 = x3_pow2_scale(max(np.abs(w).max() for w in mats["h2"]))
     n_tasks = len(mats["h2"])
     tiles = mats["h1"].shape[0] // n_tasks // 32
-    parts.append(x3_stream_heads(x3_frags(mats["h1"], sh1), [x3_frags(w, sh2) for w in mats["h2"]], tiles))
+    parts.append(s_heads(frags(mats["h1"], sh1), [frags(w, sh2) for w in mats["h2"]], tiles))
     stream = np.concatenate(parts)
     assert stream.shape[0] % 16 == 0
     return {"stream": stream, "chunks": stream.shape[0] // 16, "sw_h1": sh1, "sw_h2": sh2,
@@ -290,7 +349,8 @@ def x3_eligible(sd: Dict, fuse_attention: bool) -> bool:
 
 
 def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int, device, ln_eps=1e-5,
-                fuse_attention: bool = True, x6: bool = True, x3: bool = False, x3_min_rows: int = 0):
+                fuse_attention: bool = True, x6: bool = True, x3: bool = False, x3_min_rows: int = 0,
+                x3_variant: int = 32):
     """state_dict-like of the reference TransformerRanker -> (RankerParams, Packed, task names).
     ``fuse_attention``: pre-multiply W_ov = W_o W_v, b_ov = W_o b_v + b_o in float64 (the seq-len-1
     attention is exactly W_o(W_v x + b_v) + b_o, transformer_ranker.py:59-88 with :358), so each
@@ -396,7 +456,8 @@ def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int
         mats["h1"], mats["hb1"] = f32(w1), f32(b1)
         for t in tasks:
             mats["h2"].append(f32(_np64(sd[f"prediction_heads.{t}.3.weight"])))
-        x = pack_x3_stream(mats)
+        x = pack_x3_stream(mats, x3_variant)
+        p.x3.variant = x3_variant
         lay = []
         for li in range(p.n_layers):
             pre = f"transformer_layers.{li}"

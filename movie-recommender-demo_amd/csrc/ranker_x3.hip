@@ -2,6 +2,7 @@
 //   ranker_x3_kernel : input rows (dense X or cached-projection gather) -> all phases of the chain -> logits
 //   amdrec_ranker_x3_prefix : debugging / test entry: run the first n phases on a dense X and return the rows
 #include "rowowner.hpp"
+#include "rowowner16.hpp"
 #include "../../include/amdrec.h"
 
 using namespace amdrec;
@@ -17,6 +18,7 @@ static long long x3_param_floats(const amdrec_ranker_params* p) {
 // eligibility of the engine for these parameters (the reference architecture: d_model 256, 64-wide head layer 2)
 static bool x3_eligible(const amdrec_ranker_params* p) {
     if (p->x3.stream == nullptr || p->x3.chunks <= 0 || p->x3.params == nullptr) return false;
+    if (p->x3.variant != 16 && p->x3.variant != 32) return false;
     if (x3_param_floats(p) > x3::PARAM_FLOATS) return false;      // the parameter blob must fit its LDS area
     if (p->d_model != 256 || p->d_ff % 32 != 0 || p->head_h1 % 32 != 0 || p->head_h2 != 64) return false;
     if (2 * p->n_layers + p->n_cross + 1 > x3::MAX_PHASES || p->n_tasks > 4) return false;
@@ -72,10 +74,12 @@ static size_t x3_scratch_bytes(long long rows) {
 }
 
 static int x3_launch(const x3::Program& G, const x3::Input& in, long long rows, float* scratch, float* x_out,
-                     long long ld_xout, float* logits, long long ld_logits, hipStream_t st) {
+                     long long ld_xout, float* logits, long long ld_logits, hipStream_t st, int variant) {
     static PerDeviceOnce attr_done;
     if (attr_done.pending()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(x3::ranker_x3_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(x3b::ranker_x3b_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
         attr_done.mark();
     }
@@ -89,9 +93,14 @@ static int x3_launch(const x3::Program& G, const x3::Input& in, long long rows, 
             else if (P.type == x3::PH_FFN_LN) w += 2.0 * 256.0 * 32.0 * P.n_steps;
             else w += (double)P.n_tasks * (256.0 * 32.0 * P.n_steps + 64.0 * 32.0 * P.n_steps + 64.0);
         }
-        ProfScope prof("ranker_rowowner_128_x3", 2.0 * (double)rows * w, (double)rows * (1024.0 + 12.0), st);
-        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES + x3::PARAM_FLOATS * 4, st, G, in, rows, scratch, x_out,
-                           ld_xout, logits, ld_logits);
+        ProfScope prof(variant == 16 ? "ranker_rowowner16_128_x3" : "ranker_rowowner_128_x3", 2.0 * (double)rows * w,
+                       (double)rows * (1024.0 + 12.0), st);
+        if (variant == 16)
+            hipLaunchKernelGGL(x3b::ranker_x3b_kernel, dim3(grid), dim3(512), x3::RING_BYTES + x3::PARAM_FLOATS * 4, st, G, in,
+                               rows, scratch, x_out, ld_xout, logits, ld_logits);
+        else
+            hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES + x3::PARAM_FLOATS * 4, st, G, in,
+                               rows, scratch, x_out, ld_xout, logits, ld_logits);
     }
     HIP_TRY(hipGetLastError());
     return AMDREC_OK;
@@ -117,7 +126,7 @@ int ranker_x3_run(const amdrec_ranker_params* p, const float* X, long long ldx, 
         in.cache = p->ad_proj_cache; in.ldc = p->ld_ad_proj_cache; in.n_cache = n_cache; in.rowmap = rowmap; in.U = U;
         in.row_base = row_base; in.rowdiv = rowdiv;
     }
-    return x3_launch(G, in, rows, scratch, nullptr, 0, logits, ld_logits, st);
+    return x3_launch(G, in, rows, scratch, nullptr, 0, logits, ld_logits, st, (int)p->x3.variant);
 }
 }  // namespace amdrec
 
@@ -140,5 +149,5 @@ extern "C" int amdrec_ranker_x3_prefix(const amdrec_ranker_params* p, const floa
     x3::Input in{};
     in.X = X; in.ldx = ldx;
     return x3_launch(G, in, rows, reinterpret_cast<float*>(workspace), x_out, ld_out, logits, ld_logits,
-                     reinterpret_cast<hipStream_t>(stream));
+                     reinterpret_cast<hipStream_t>(stream), (int)p->x3.variant);
 }

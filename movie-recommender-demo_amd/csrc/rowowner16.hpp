@@ -1,0 +1,432 @@
+// Row-owner engine, 16-rows-per-wave variant ("x3b"): the same chain, arithmetic, weight-stream ring and parameter blob as
+// rowowner.hpp, re-tiled so that TWO waves share each SIMD.
+//
+// WHY.  The 32-row kernel needs ~350 registers per wave (planes 128 + accumulators 128 + ...), i.e. one wave per SIMD, and
+// at one wave per SIMD every non-MFMA instruction is exposed: elimination runs (tools/x3_probe.hip) put its MFMA + VALU
+// floor at 0.50 of the fp16/3 bound with all memory traffic removed - row scaling, the fp16 plane split, LayerNorm and the
+// accumulator moves of ten phase transitions run while the matrix pipe idles.  Here a wave owns 16 rows on
+// v_mfma_f32_16x16x32_f16 (same FLOP rate per cycle as 32x32x16): planes 64 + accumulators 64 registers, ~210 in all, so a
+// workgroup is 8 waves = 128 rows and the two waves of a SIMD overlap one's VALU / LDS latency with the other's MFMAs.
+// The price: an A fragment (1 KB) now feeds a 16-cycle MFMA instead of a 32-cycle one, so LDS fragment traffic doubles
+// (~66 % of the LDS read rate at full MFMA speed); fragment sets, chunks, ring and parameter blob are unchanged in size.
+//
+// GEOMETRY.  lane l: row q = l & 15, group g = l >> 4.  State x[16] (f32x4 tiles): x[T][r] = feature 16 T + 4 g + r.
+//   A operand: lane (p, g) holds A[p][k = 8 g + j];  B: lane (q, g) holds B[k = 8 g + j][q];  D: D[p = 4 g + r][q].
+//   A k-step is 32 features = tiles 2 ks and 2 ks + 1: B element j = x[2 ks + (j >> 2)][j & 3], i.e. k position 8 g + j is
+//   feature 32 ks + 16 (j >> 2) + 4 g + (j & 3); the host packs the A fragments with the same permutation
+//   (amdrec/weights.py x3b_frags).  Stream orders mirror rowowner.hpp with 16-feature output tiles:
+//     gemm256 : for ks < 8: for tile pair tp < 8: {A_h(2tp, ks), A_l(2tp, ks), A_h(2tp+1, ks), A_l(2tp+1, ks)}
+//     ffn step t: for u < 8: stage 1 {W_1 tiles 2t, 2t+1 at ks = u}, then stage 2 {W_2 tiles 2u, 2u+1 at k-step t-1}
+//     heads, per task and hidden tile (32): stage 1 as above (8 groups), stage 2 {W_2 tiles 0,1}, {tiles 2,3} at k-step t
+#pragma once
+#include "rowowner.hpp"
+
+namespace amdrec {
+namespace x3b {
+
+using x3::CHUNK_BYTES;
+using x3::CHUNK_FRAGS;
+using x3::DBG;
+using x3::f16x8;
+using x3::FRAG_BYTES;
+using x3::Input;
+using x3::lds_byte;
+using x3::lds_cfloat;
+using x3::NBUF;
+using x3::PARAM_FLOATS;
+using x3::Phase;
+using x3::Program;
+using x3::RING_BYTES;
+using x3::TARGET_EXP;
+using x3::DEPTH;
+
+constexpr int WAVES = 8, ROWS_PER_WAVE = 16, ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
+constexpr int DMA_PER_WAVE = CHUNK_FRAGS / WAVES;     // 2 fragment sets per wave and chunk
+
+struct Ring {
+    const unsigned char* gsrc;
+    lds_byte* lds_dma;
+    lds_byte* lds_rd;
+    int issued, total;
+    uint32_t rpos;
+    int rfrags;
+
+    __device__ __forceinline__ void issue() {
+        if (DBG & 1) { ++issued; return; }
+        const int c = issued < total ? issued : total - 1;
+        const unsigned char* src = gsrc + (size_t)c * CHUNK_BYTES;
+        lds_byte* dst = lds_dma + (uint32_t)(issued % NBUF) * CHUNK_BYTES;
+#pragma unroll
+        for (int u = 0; u < DMA_PER_WAVE; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * FRAG_BYTES),
+                                             (__attribute__((address_space(3))) void*)(dst + u * FRAG_BYTES), 16, 0, 0);
+        ++issued;
+    }
+    __device__ __forceinline__ void certify_next() {
+        if (!(DBG & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * (DEPTH - 1)) : "memory");
+        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+        issue();
+    }
+    __device__ __forceinline__ void start(const unsigned char* stream, int total_chunks, lds_byte* lds, int wave, int lane) {
+        gsrc = stream + wave * DMA_PER_WAVE * FRAG_BYTES + lane * 16;
+        lds_dma = lds + wave * DMA_PER_WAVE * FRAG_BYTES;
+        lds_rd = lds + lane * 16;
+        issued = 0;
+        total = total_chunks;
+        rpos = 0;
+        rfrags = 0;
+#pragma unroll
+        for (int c = 0; c < DEPTH + 1; ++c) issue();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * DEPTH) : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    __device__ __forceinline__ void read4(f16x8 (&f)[4]) {
+        if ((rfrags & (CHUNK_FRAGS - 1)) == 0) certify_next();
+        const lds_byte* a = lds_rd + rpos;
+        if ((DBG & 4) && rfrags != 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(f[u]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                f[u] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(a + u * FRAG_BYTES);
+        }
+        rpos += 4 * FRAG_BYTES;
+        if (rpos >= RING_BYTES) rpos -= RING_BYTES;
+        rfrags += 4;
+    }
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+__device__ __forceinline__ f32x4 mfma(const f16x8& a, const f16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// one group of 4 fragment sets {Ah(t0), Al(t0), Ah(t1), Al(t1)} against one B k-step (bh, bl): 6 MFMAs, two accumulators interleaved
+__device__ __forceinline__ void group6(const f16x8 (&a)[4], const f16x8& bh, const f16x8& bl, f32x4& c0, f32x4& c1) {
+    c0 = mfma(a[0], bl, c0);
+    c1 = mfma(a[2], bl, c1);
+    c0 = mfma(a[1], bh, c0);
+    c1 = mfma(a[3], bh, c1);
+    c0 = mfma(a[0], bh, c0);
+    c1 = mfma(a[2], bh, c1);
+}
+
+__device__ __forceinline__ float reduce_max4(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float reduce_sum4(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ void row_scale(const f32x4 (&x)[16], float& s, float& inv) {
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fabsf(x[t][r]));
+    m = reduce_max4(m);
+    int eb = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    eb = eb < 87 ? 87 : (eb > 250 ? 250 : eb);                  // see rowowner.hpp row_scale
+    s = __uint_as_float((uint32_t)(127 + TARGET_EXP + 127 - eb) << 23);
+    inv = __uint_as_float((uint32_t)(eb - TARGET_EXP) << 23);
+}
+
+// planes of one k-step from two adjacent tiles (elements 0..3 from `a`, 4..7 from `b`), scaled by s
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, float s, f16x8& h, f16x8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = (j < 4 ? a[j & 3] : b[j & 3]) * s;
+        const _Float16 hh = (_Float16)v;
+        h[j] = hh;
+        l[j] = (_Float16)(v - (float)hh);
+    }
+}
+
+__device__ __forceinline__ f32x4 param4(lds_cfloat* pb, int off, int tile) {      // features 16 tile + 4 g + {0..3} (pb carries 4 g)
+    return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(pb + off + 16 * tile);
+}
+
+// planes + initial accumulators, tile pair by tile pair (x[2ks], x[2ks+1] die as they are consumed)
+template <bool WITH_X>
+__device__ __forceinline__ void prepare(const f32x4 (&x)[16], float s, lds_cfloat* pb, int bias, float scale,
+                                        f16x8 (&xh)[8], f16x8 (&xl)[8], f32x4 (&acc)[16]) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        split8(x[2 * ks], x[2 * ks + 1], s, xh[ks], xl[ks]);
+#pragma unroll
+        for (int t = 2 * ks; t < 2 * ks + 2; ++t) {
+            const f32x4 b = param4(pb, bias, t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = ((WITH_X ? x[t][r] : 0.f) + b[r]) * scale;
+        }
+    }
+}
+
+__device__ __forceinline__ void gemm256(Ring& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4 (&acc)[16]) {
+    f16x8 cur[4], nxt[4];
+    ring.read4(cur);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int tp = 0; tp < 8; ++tp) {
+            const bool last = ks == 7 && tp == 7;
+            if (!last) ring.read4(nxt);
+            group6(cur, xh[ks], xl[ks], acc[2 * tp], acc[2 * tp + 1]);
+            if (!last) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            }
+        }
+}
+
+__device__ __forceinline__ void layer_norm(f32x4 (&y)[16], lds_cfloat* pb, int gamma, int beta, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += y[t][r];
+    const float mean = reduce_sum4(s) * (1.0f / 256.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = y[t][r] - mean;
+            q += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(reduce_sum4(q) * (1.0f / 256.0f) + eps);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const f32x4 ga = param4(pb, gamma, t), be = param4(pb, beta, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[t][r] = (y[t][r] - mean) * rstd * ga[r] + be[r];
+    }
+}
+
+__device__ __forceinline__ void phase_attn_ln(Ring& ring, const Phase& P, f32x4 (&x)[16], lds_cfloat* pb) {
+    float s, inv;
+    row_scale(x, s, inv);
+    f16x8 xh[8], xl[8];
+    f32x4 acc[16];
+    prepare<true>(x, s, pb, P.b1, s * P.sw1, xh, xl, acc);
+    gemm256(ring, xh, xl, acc);
+    const float un = inv / P.sw1;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[t][r] = acc[t][r] * un;
+    layer_norm(x, pb, P.gamma, P.beta, P.ln_eps);
+}
+
+// hidden tile (two 16-feature accumulators = one k-step of stage 2) -> planes
+__device__ __forceinline__ void hidden_planes(const f32x4& a0, const f32x4& a1, float c, f16x8& hh, f16x8& hl) {
+    if (DBG & 8) {
+        asm volatile("" : "+v"(hh), "+v"(hl) : "v"(a0), "v"(a1));
+        return;
+    }
+    f32x4 t0, t1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        t0[r] = fminf(fmaxf(a0[r], 0.f) * c, 60000.f);
+        t1[r] = fminf(fmaxf(a1[r], 0.f) * c, 60000.f);
+    }
+    split8(t0, t1, 1.0f, hh, hl);
+}
+__device__ __forceinline__ void init_pair(f32x4& a0, f32x4& a1, lds_cfloat* pb, int bias, int tile0, float scale) {
+    const f32x4 b0 = param4(pb, bias, tile0), b1 = param4(pb, bias, tile0 + 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        a0[r] = b0[r] * scale;
+        a1[r] = b1[r] * scale;
+    }
+}
+
+// One FFN step: 8 x { stage-1 group (W_1 tiles 2t, 2t+1 at ks = u), stage-2 group (W_2 tiles 2u, 2u+1 at k-step t-1) }
+template <bool S1, bool S2>
+__device__ __forceinline__ void ffn_step(Ring& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4& a10, f32x4& a11,
+                                         f32x4 (&acc2)[16], const f16x8& hh, const f16x8& hl) {
+    constexpr int NG = (S1 ? 8 : 0) + (S2 ? 8 : 0);          // groups in this step
+    f16x8 cur[4], nxt[4];
+    ring.read4(cur);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi < NG - 1) ring.read4(nxt);
+        const bool is1 = S1 && (!S2 || (gi & 1) == 0);
+        const int u = (S1 && S2) ? gi >> 1 : gi;
+        if (is1) group6(cur, xh[u], xl[u], a10, a11);
+        else group6(cur, hh, hl, acc2[2 * u], acc2[2 * u + 1]);
+        if (gi < NG - 1) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cur[v] = nxt[v];
+        }
+    }
+}
+
+__device__ __forceinline__ void phase_ffn_ln(Ring& ring, const Phase& P, f32x4 (&x)[16], lds_cfloat* pb) {
+    float s, inv;
+    row_scale(x, s, inv);
+    f16x8 xh[8], xl[8];
+    const float sh = x3::hidden_scale(fmaf(P.hn * 8192.0f, inv, P.hb));
+    f32x4 acc2[16];
+    prepare<true>(x, s, pb, P.b2, P.sw2 * sh, xh, xl, acc2);
+    const float b1s = s * P.sw1, c1 = sh * inv / P.sw1;
+    f32x4 a10, a11;
+    f16x8 hh, hl;
+    init_pair(a10, a11, pb, P.b1, 0, b1s);
+    ffn_step<true, false>(ring, xh, xl, a10, a11, acc2, hh, hl);
+    for (int t = 1; t < P.n_steps; ++t) {
+        hidden_planes(a10, a11, c1, hh, hl);
+        init_pair(a10, a11, pb, P.b1, 2 * t, b1s);
+        ffn_step<true, true>(ring, xh, xl, a10, a11, acc2, hh, hl);
+    }
+    hidden_planes(a10, a11, c1, hh, hl);
+    ffn_step<false, true>(ring, xh, xl, a10, a11, acc2, hh, hl);
+    const float un = 1.0f / (P.sw2 * sh);
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[t][r] = acc2[t][r] * un;
+    layer_norm(x, pb, P.gamma, P.beta, P.ln_eps);
+}
+
+// row I/O: lane (q, g) moves the 16-byte groups [16 T + 4 g, +4) of row q (64 contiguous bytes per row and instruction)
+__device__ __forceinline__ void load_rows(f32x4 (&x)[16], const float* row_ptr, int g) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) x[t] = *reinterpret_cast<const f32x4*>(row_ptr + 16 * t + 4 * g);
+}
+__device__ __forceinline__ void add_rows(f32x4 (&x)[16], const float* row_ptr, int g) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row_ptr + 16 * t + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[t][r] += v[r];
+    }
+}
+__device__ __forceinline__ void store_rows(const f32x4 (&x)[16], float* row_ptr, int g) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(row_ptr + 16 * t + 4 * g) = x[t];
+}
+
+__device__ __forceinline__ void phase_cross(Ring& ring, const Phase& P, f32x4 (&xl_)[16], const float* x0_row, int g,
+                                            lds_cfloat* pb) {
+    float s, inv;
+    row_scale(xl_, s, inv);
+    f16x8 xh[8], xl[8];
+    f32x4 acc[16];
+    prepare<false>(xl_, s, pb, P.b1, s * P.sw1, xh, xl, acc);
+    gemm256(ring, xh, xl, acc);
+    const float un = inv / P.sw1;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x0_row + 16 * t + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xl_[t][r] = v0[r] * (acc[t][r] * un) + xl_[t][r];
+    }
+}
+
+__device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const Phase& P, const f32x4 (&x)[16], float* out,
+                                            long long ld_out, long long row, bool row_ok, int g, lds_cfloat* pb) {
+    float s, inv;
+    row_scale(x, s, inv);
+    f16x8 xh[8], xl[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) split8(x[2 * ks], x[2 * ks + 1], s, xh[ks], xl[ks]);
+    const float sh = x3::hidden_scale(fmaf(P.hn * 8192.0f, inv, P.hb));
+    const float b1s = s * P.sw1, c1 = sh * inv / P.sw1, un2 = 1.0f / (P.sw2 * sh);
+    for (int task = 0; task < P.n_tasks; ++task) {
+        f32x4 acc2[4];
+        init_pair(acc2[0], acc2[1], pb, G.hb2[task], 0, P.sw2 * sh);
+        init_pair(acc2[2], acc2[3], pb, G.hb2[task], 2, P.sw2 * sh);
+        for (int t = 0; t < P.n_steps; ++t) {
+            f32x4 a10, a11;
+            init_pair(a10, a11, pb, P.b1 + task * P.n_steps * 32, 2 * t, b1s);
+            f16x8 cur[4], nxt[4];
+            ring.read4(cur);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u < 7) ring.read4(nxt);
+                group6(cur, xh[u], xl[u], a10, a11);
+                if (u < 7) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) cur[v] = nxt[v];
+                }
+            }
+            f16x8 hh, hl;
+            hidden_planes(a10, a11, c1, hh, hl);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                ring.read4(cur);
+                group6(cur, hh, hl, acc2[2 * pr], acc2[2 * pr + 1]);
+            }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 w = param4(pb, G.hw3[task], t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot += fmaxf(acc2[t][r] * un2, 0.f) * w[r];
+        }
+        dot = reduce_sum4(dot);
+        if (g == 0 && row_ok) out[(long long)task * ld_out + row] = dot + pb[G.hb3[task]];      // g == 0: pb carries no offset
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void ranker_x3b_kernel(Program G, Input in, long long rows, float* scratch,
+                                                            float* x_out, long long ld_xout, float* logits,
+                                                            long long ld_logits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, q = lane & 15;
+    const long long row = (long long)blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE + q;
+    const bool row_ok = row < rows;
+    const long long rowc = row_ok ? row : rows - 1;
+
+    lds_byte* pbase = (lds_byte*)smem + RING_BYTES;
+    for (int o = 0; o + wave * 1024 < G.n_params * 4; o += 8192)        // 8 waves x 1 KB per pass; n_params % 1024 == 0
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(
+                                             reinterpret_cast<const unsigned char*>(G.params) + o + tid * 16),
+                                         (__attribute__((address_space(3))) void*)(pbase + o + wave * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_cfloat* pb = reinterpret_cast<lds_cfloat*>(pbase) + 4 * g;
+
+    Ring ring;
+    ring.start(G.stream, G.total_chunks, (lds_byte*)smem, wave, lane);
+
+    f32x4 x[16];
+    if (in.X != nullptr) {
+        load_rows(x, in.X + rowc * in.ldx, g);
+    } else {
+        const long long gr = in.row_base + rowc;
+        long long a = in.rowmap ? in.rowmap[gr] : gr;
+        a = a < 0 ? 0 : (a >= in.n_cache ? in.n_cache - 1 : a);
+        load_rows(x, in.cache + a * in.ldc, g);
+        add_rows(x, in.U + (gr / in.rowdiv) * 256, g);
+    }
+    float* x0_row = scratch + row * 256;
+    bool x0_saved = false;
+    for (int p = 0; p < G.n_phases; ++p) {
+        const Phase& P = G.ph[p];
+        const int type = __builtin_amdgcn_readfirstlane(P.type);
+        if (type == x3::PH_ATTN_LN) {
+            phase_attn_ln(ring, P, x, pb);
+        } else if (type == x3::PH_FFN_LN) {
+            phase_ffn_ln(ring, P, x, pb);
+        } else if (type == x3::PH_CROSS) {
+            if (!x0_saved) {
+                store_rows(x, x0_row, g);
+                x0_saved = true;
+            }
+            phase_cross(ring, P, x, x0_row, g, pb);
+        } else {
+            phase_heads(ring, G, P, x, logits, ld_logits, row, row_ok, g, pb);
+        }
+    }
+    if (x_out != nullptr && row_ok) store_rows(x, x_out + row * ld_xout, g);
+    ring.drain();
+}
+
+}  // namespace x3b
+}  // namespace amdrec

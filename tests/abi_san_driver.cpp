@@ -96,7 +96,7 @@ int main() {
     EXPECT(amdrec_ranker_project_ads(&rp, ip, 10, fp, 256, fake, 4096, nullptr) < 0);                              // no split projection
     // fp16x3 engine: eligibility and stream-length checks are host logic
     EXPECT(amdrec_ranker_x3_prefix(&rp, fp, 256, 10, -1, fp, 256, fp, 10, fake, 4096, nullptr) < 0);               // no stream
-    rp.x3.stream = fake; rp.x3.chunks = 5;
+    rp.x3.stream = fake; rp.x3.chunks = 5; rp.x3.variant = 32;
     EXPECT(amdrec_ranker_x3_prefix(&rp, fp, 256, 10, -1, fp, 256, fp, 10, fake, 4096, nullptr) < 0);               // no parameter blob
     rp.x3.params = fp; rp.x3.n_params = 7;
     EXPECT(amdrec_ranker_x3_prefix(&rp, fp, 256, 10, -1, fp, 256, fp, 10, fake, 4096, nullptr) < 0 &&

@@ -15,11 +15,24 @@ from tests import cases
 pytestmark = pytest.mark.gpu
 
 
+VARIANT = 32
+
+
+@pytest.fixture(params=[32, 16], autouse=True)
+def variant(request):
+    """Every case runs on both row-owner kernels: 32 rows per wave (rowowner.hpp) and 16 rows per wave (rowowner16.hpp)."""
+    global VARIANT
+    VARIANT = request.param
+    yield request.param
+    VARIANT = 32
+
+
 def _model(name, cross):
     from amdrec.ranker import TransformerRanker
     user, ad, nnum, sd, _ = cases.ranker_case(name, cross)
     m = TransformerRanker(dict(user), dict(ad), nnum)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m.x3_variant = VARIANT
     return m.cuda().eval(), sd, (user, ad, nnum)
 
 
@@ -67,7 +80,7 @@ def test_every_prefix_of_the_chain_matches_float64(cross, accuracy):
             scale = np.abs(ref).max(axis=1, keepdims=True)            # per-row magnitude
             err = float((np.abs(x - ref) / scale).max())
             err32 = float((np.abs(f32[n - 1] - ref) / scale).max())   # the numpy fp32 evaluation of the same prefix
-            accuracy(f"x3_prefix/demo_{cross}/{names[n - 1]}", "f16x3", err / max(err32, 1e-30),
+            accuracy(f"x3_prefix/demo_{cross}/{names[n - 1]}", f"f16x3/{VARIANT}", err / max(err32, 1e-30),
                      rel_err_vs_float64=err, numpy_fp32_rel_err_vs_float64=err32)
             assert np.isfinite(x).all(), names[n - 1]
             assert err <= 4 * err32 + 2e-6, (names[n - 1], err, err32)
@@ -75,7 +88,7 @@ def test_every_prefix_of_the_chain_matches_float64(cross, accuracy):
             scale = cases.logit_scale(truth[-1])
             for ti, t in enumerate(oracle.ranker.TASKS):
                 ok, e = cases.logit_close(logits[ti], truth[-1][t], cross, scale=scale)
-                accuracy(f"x3_prefix/demo_{cross}/heads/{t}", "f16x3", e)
+                accuracy(f"x3_prefix/demo_{cross}/heads/{t}", f"f16x3/{VARIANT}", e)
                 assert ok, (t, e)
 
 
@@ -93,7 +106,7 @@ def test_x3_whole_forward_small_batches_match_reference_golden(accuracy):
             scale = cases.logit_scale({t: g[f"B{B}_{t}"] for t in pred})
             for t in pred:
                 ok, err = cases.logit_close(pred[t].cpu().numpy(), g[f"B{B}_{t}"], cross, scale=scale)
-                accuracy(f"golden/demo_{cross}/B{B}/{t}", "f16x3", err)
+                accuracy(f"golden/demo_{cross}/B{B}/{t}", f"f16x3/{VARIANT}", err)
                 assert ok, (cross, B, t, err)
 
 

@@ -163,3 +163,123 @@ def test_plane_split_is_22_bit_accurate_and_in_fp16_range():
     big = np.abs(w32) * s >= 2.0 ** -3                   # elements whose low plane is a normal fp16 number
     assert (err[big] <= 2.0 ** -22 * np.abs(w32[big])).all()
     assert (err[~big] <= 2.0 ** -25 / s).all()
+
+
+# ---- the 16-rows-per-wave variant (csrc/rowowner16.hpp): v_mfma_f32_16x16x32_f16 lane semantics --------------------
+def _b16(x):
+    """rows x [16 q][256] -> B fragments [8 ks][64 lanes][8]: lane (q, g) element j = x[2 ks + (j >> 2)][j & 3] with
+    tile T register r = feature 16 T + 4 g + r"""
+    out = np.zeros((8, 64, 8), F)
+    for ks in range(8):
+        for g in range(4):
+            for j in range(8):
+                out[ks, 16 * g:16 * g + 16, j] = x[:, 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3)]
+    return out
+
+
+def _mfma16(a, b):
+    d = np.zeros((16, 16), F)
+    for g in range(4):
+        d += a[16 * g:16 * g + 16] @ b[16 * g:16 * g + 16].T
+    return d
+
+
+def _hidden16(h32):
+    """hidden rows [16 q][32] (natural feature order) -> the single B fragment [64][8] of their k-step"""
+    out = np.zeros((64, 8), F)
+    for g in range(4):
+        for j in range(8):
+            out[16 * g:16 * g + 16, j] = h32[:, 16 * (j >> 2) + 4 * g + (j & 3)]
+    return out
+
+
+def _group(st, b, acc, t0):
+    a = st.read(4)
+    acc[t0] += _mfma16(a[0] + a[1], b)
+    acc[t0 + 1] += _mfma16(a[2] + a[3], b)
+
+
+def test_16_row_variant_stream_order_and_k_permutation():
+    user, ad, nnum, sd, _ = cases.ranker_case("demo", "scaled")
+    p, pk, tasks = weights.pack_ranker(sd, list(user), list(ad), nnum, "cpu", x3=True, x3_variant=16)
+    assert p.x3.variant == 16 and p.x3.chunks == 3 * (16 + 128) + 3 * 16 + 60
+    stream = [t for t in pk._keep if t.data_ptr() == p.x3.stream][0].numpy().view(np.uint16).reshape(-1, 64, 8)
+    st = Stream(stream)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((16, 256))
+    f64 = lambda k: np.asarray(sd[k], dtype=F)     # noqa: E731
+    rows = lambda acc: np.concatenate([t.T for t in acc], axis=1)     # noqa: E731
+
+    def gemm256():
+        acc = [np.zeros((16, 16), F) for _ in range(16)]
+        xb = _b16(x)
+        for ks in range(8):
+            for tp in range(8):
+                _group(st, xb[ks], acc, 2 * tp)
+        return rows(acc)
+
+    for l in range(3):
+        pre = f"transformer_layers.{l}"
+        wov = (f64(pre + ".self_attention.W_o.weight") @ f64(pre + ".self_attention.W_v.weight")).astype(np.float32).astype(F)
+        got = gemm256() / p.x3.sw_ov[l]
+        assert np.abs(got - x @ wov.T).max() <= 1e-5 * np.abs(x @ wov.T).max(), ("ov", l)
+        w1, b1, w2 = f64(pre + ".feed_forward.fc1.weight"), f64(pre + ".feed_forward.fc1.bias"), f64(pre + ".feed_forward.fc2.weight")
+        acc2 = [np.zeros((16, 16), F) for _ in range(16)]
+        xb, hb = _b16(x), None
+        for t in range(33):
+            a1 = [np.zeros((16, 16), F), np.zeros((16, 16), F)]
+            for u in range(8):
+                if t < 32:
+                    _group(st, xb[u], a1, 0)
+                if t >= 1:
+                    _group(st, hb, acc2, 2 * u)
+            if t < 32:
+                hb = _hidden16(np.maximum(rows(a1) / p.x3.sw_1[l] + b1[32 * t:32 * t + 32][None, :], 0))
+        got = rows(acc2) / p.x3.sw_2[l]
+        ref = np.maximum(x @ w1.T + b1, 0) @ w2.T
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), ("ffn", l)
+    for c in range(3):
+        wc = f64(f"feature_interaction.cross_weights.{c}")
+        got = gemm256() / p.x3.sw_cross[c]
+        assert np.abs(got - x @ wc).max() <= 1e-5 * np.abs(x @ wc).max(), ("cross", c)
+    xb = _b16(x)
+    for t in tasks:
+        w1, b1, w2 = f64(f"prediction_heads.{t}.0.weight"), f64(f"prediction_heads.{t}.0.bias"), f64(f"prediction_heads.{t}.3.weight")
+        acc2 = [np.zeros((16, 16), F) for _ in range(4)]
+        for tt in range(8):
+            a1 = [np.zeros((16, 16), F), np.zeros((16, 16), F)]
+            for u in range(8):
+                _group(st, xb[u], a1, 0)
+            hb = _hidden16(np.maximum(rows(a1) / p.x3.sw_h1 + b1[32 * tt:32 * tt + 32][None, :], 0))
+            for pr in range(2):
+                _group(st, hb, acc2, 2 * pr)
+        got = rows(acc2) / p.x3.sw_h2
+        ref = np.maximum(x @ w1.T + b1, 0) @ w2.T
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), ("head", t)
+    assert st.pos == stream.shape[0]
+
+
+def test_parameter_blob_layout_matches_the_kernels_offsets():
+    """pack_x3_params vs the offsets csrc/ranker_x3.hip x3_build derives from the architecture."""
+    user, ad, nnum, sd, _ = cases.ranker_case("demo", "scaled")
+    p, pk, tasks = weights.pack_ranker(sd, list(user), list(ad), nnum, "cpu", x3=True)
+    blob = [t for t in pk._keep if t.data_ptr() == p.x3.params][0].numpy()
+    assert len(blob) == p.x3.n_params == 10240 and len(blob) % 1024 == 0
+    o = 0
+    for l in range(3):
+        pre = f"transformer_layers.{l}"
+        assert np.array_equal(blob[o + 256:o + 512], sd[pre + ".norm1.weight"])
+        assert np.array_equal(blob[o + 768:o + 768 + 1024], sd[pre + ".feed_forward.fc1.bias"])
+        assert np.array_equal(blob[o + 768 + 1024 + 512:o + 768 + 1024 + 768], sd[pre + ".norm2.bias"])
+        o += 1536 + 1024
+    for c in range(3):
+        assert np.array_equal(blob[o:o + 256], sd[f"feature_interaction.cross_biases.{c}"])
+        o += 256
+    assert np.array_equal(blob[o:o + 256], sd["prediction_heads.ctr.0.bias"])
+    o += 768
+    for t in tasks:
+        assert np.array_equal(blob[o:o + 64], sd[f"prediction_heads.{t}.3.bias"])
+        assert np.array_equal(blob[o + 64:o + 128], sd[f"prediction_heads.{t}.6.weight"].reshape(-1))
+        assert blob[o + 128] == sd[f"prediction_heads.{t}.6.bias"][0]
+        o += 132
+    assert not blob[o:].any()

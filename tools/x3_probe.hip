@@ -7,6 +7,17 @@
 #include <cstdlib>
 #include <vector>
 #include "../movie-recommender-demo_amd/csrc/rowowner.hpp"
+#include "../movie-recommender-demo_amd/csrc/rowowner16.hpp"
+#ifndef AMDREC_X3_VARIANT
+#define AMDREC_X3_VARIANT 32
+#endif
+#if AMDREC_X3_VARIANT == 16
+#define KERNEL x3b::ranker_x3b_kernel
+#define NTHREADS 512
+#else
+#define KERNEL x3::ranker_x3_kernel
+#define NTHREADS 256
+#endif
 using namespace amdrec;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -52,24 +63,24 @@ int main(int argc, char** argv) {
     G.n_phases = n; G.total_chunks = (int)chunks; G.stream = (const unsigned char*)dstream;
     x3::Input in{};
     in.X = dX; in.ldx = 256;
-    CK(hipFuncSetAttribute((const void*)x3::ranker_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
+    CK(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
     const unsigned grid = (unsigned)((rows + 127) / 128);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES + x3::PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(NTHREADS), x3::RING_BYTES + x3::PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
     CK(hipDeviceSynchronize());
     const int reps = 10;
     CK(hipEventRecord(e0));
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(x3::ranker_x3_kernel, dim3(grid), dim3(256), x3::RING_BYTES + x3::PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(NTHREADS), x3::RING_BYTES + x3::PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
     const double flop = 2.0 * rows * (L * (65536.0 + 2 * 262144.0) + C * 65536.0 + T * (65536.0 + 16384.0 + 64.0));
-    printf("DBG=%d rows=%lld: %.3f ms  %.1f TF fp32-equivalent  (%.3f of 833 TF)\n", AMDREC_X3_DBG, rows, ms, flop / ms / 1e9,
+    printf("variant=%d DBG=%d rows=%lld: %.3f ms  %.1f TF fp32-equivalent  (%.3f of 833 TF)\n", AMDREC_X3_VARIANT, AMDREC_X3_DBG, rows, ms, flop / ms / 1e9,
            flop / ms / 1e9 / 833.3);
     return 0;
 }
