@@ -33,6 +33,8 @@ def short(name):
         return f"{epi}_256x128_x6"
     if "scan_filter_kernel" in name:
         return "search_filter_stream128x512_bf16"
+    if "ranker_x3b_kernel" in name:
+        return "ranker_rowowner16_128_x3"
     if "ranker_x3_kernel" in name:
         return "ranker_rowowner_128_x3"
     if "finalize_mixed_kernel" in name:
@@ -74,6 +76,11 @@ def main():
             e["mfma_busy_frac"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (g * 1024)   # 256 CUs x 4 SIMDs
             if c.get("SQ_WAVE_CYCLES"):
                 e["wave_wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        if "TCC_HIT_sum" in c and c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0.0) > 0:
+            e["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        for k2 in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS"):
+            if k2 in c:
+                e[k2.lower() + "_per_launch"] = c[k2] / launches[k][k2]
         if e:
             out[k] = e
     tags = sorted(json.load(open(a.bench_json))["kernels"]) if a.bench_json else []
