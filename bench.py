@@ -328,7 +328,7 @@ def main():
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "arithmetic": ("fp32 in / fp32 out everywhere; ranker passes of > 8192 rows (engine " + rk.gemm_engine + "): "
                                "operands scaled by powers of two and split into 2 fp16 planes, 3 fp16-MFMA products per MAC, "
-                               "fp32 accumulate (logit error vs float64 = 2x the fp32-MFMA engine's, profiles/r02_accuracy.json); "
+                               "fp32 accumulate (logit error vs float64 = 2.2-2.7x the fp32-MFMA engine's, profiles/r02_accuracy.json); "
                                "search: bf16-MFMA prefilter, fp32 re-score, certified exact; everything else fp32 MFMA / fp32 VALU"),
                 "config": {"workload": ("configs[2]: 1M synthetic ads d=256, UserTower batch=512/GPU, "
                                         "exact IP top-500, TransformerRanker(256,8 heads,3 layers) on 500 cands, top-10")
