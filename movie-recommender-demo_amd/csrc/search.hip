@@ -432,8 +432,10 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, qf[j][s_], acc[j], 0, 0, 0);
         }
         // Threshold scan.  A hit is rare per element (~1.4e-3) but a taken branch per element costs more than the
-        // MFMAs it follows, so four elements share one test (their maximum; NaN never wins) and the per-element code
-        // is out of line.
+        // MFMAs it follows, so four elements share one test (their maximum; NaN never wins) and the per-element code is
+        // out of line.  (A single v_max3 tree + one test over all 16 elements of a tile was measured in a same-box A/B,
+        // profiles/r02_scan_tree16_ab.log: 25 % SLOWER at 512 queries - 0.383 vs 0.307 ms - the four short independent
+        // chains overlap with the MFMAs better than one deep one.)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -584,11 +586,18 @@ __device__ __forceinline__ float eps_rel(int d) { return 0.00783f + (float)d * 1
 // The candidate keys (<= 16 per thread) stay in registers for the selection: a 3-pass radix select of the k-th
 // largest approximate score (LDS histograms), then only the survivors of the pruning rule go to LDS, are re-scored
 // and sorted (typically ~1.25 k keys instead of the whole list).
-__global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long long* cand, const int* cnt, int cap,
+// SPLIT (small batches, <= SPLIT_MAX_NQ queries): the kernel stops after the prune and publishes the survivors (in place, at
+// the head of the query's candidate list) with their count and eps; finalize_rescore_kernel then spreads the re-scoring of
+// ONE query over several workgroups (a single block re-scoring ~1200 random 1 KB rows is latency-bound: 83 us at B = 1)
+// and finalize_sort_kernel sorts and certifies.  Large batches keep the fused form: one block per query already fills the chip.
+constexpr int SPLIT_MAX_NQ = 128;
+template <bool SPLIT>
+__global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long* cand, const int* cnt, int cap,
                                                              int k, long long nrows, const float* tau,
                                                              const float* max_norm, const float* X, long long ldx,
                                                              int d, const float* Q, long long ldq, int* fail,
-                                                             float* outD, long long* outI, long long pos_offset) {
+                                                             float* outD, long long* outI, long long pos_offset,
+                                                             int* m_out, float* eps_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [cap] then qv[d]
     float* qv = reinterpret_cast<float*>(keys + cap);
     __shared__ int hist[2048];
@@ -600,7 +609,11 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long
     const int c = cnt[q];
     const int need = (int)(nrows < k ? nrows : k);
     auto give_up = [&]() {
-        if (tid == 0) { fail[q] = 1; atomicAdd(&fail[gridDim.x], 1); }
+        if (tid == 0) {
+            fail[q] = 1;
+            atomicAdd(&fail[gridDim.x], 1);
+            if (SPLIT) m_out[q] = -1;                             // the follow-up kernels skip this query
+        }
     };
     if (c < need || c > cap) { give_up(); return; }
     float ss = 0.f;
@@ -625,7 +638,11 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long
     for (int i = 0; i < 8; ++i) qn += red[i];
     const float eps = eps_rel(d) * sqrtf(qn) * max_norm[0];
     if (!(eps < INFINITY)) { give_up(); return; }            // NaN / inf norms: exact path (block-uniform)
-    if (need == 0) { write_result(keys, 0, k, q, outD, outI, pos_offset); return; }
+    if (need == 0) {
+        write_result(keys, 0, k, q, outD, outI, pos_offset);
+        if (SPLIT && tid == 0) m_out[q] = -1;
+        return;
+    }
     // a_k = need-th largest approximate score (orderable 32-bit image), radix select 11 + 11 + 10 bits
     uint32_t prefix = 0u, pmask = 0u;
     int rr = need;
@@ -653,6 +670,11 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long
         if (tid + 512 * j < c && key_score(mine[j]) >= cut) keys[atomicAdd(&m_sh, 1)] = mine[j];
     __syncthreads();
     const int m = m_sh;                                       // need <= m <= c
+    if constexpr (SPLIT) {                                    // publish: survivors overwrite the head of the candidate list
+        for (int i = tid; i < m; i += 512) cand[(long long)q * cap + i] = keys[i];     // (every thread read its share above)
+        if (tid == 0) { m_out[q] = m; eps_out[q] = eps; }
+        return;
+    }
     // fp32 re-score, one wave per candidate, 16 candidates (random 1 KB rows: latency-bound) in flight per wave
     const int d4 = d >> 2;
     constexpr int RU = 16;
@@ -702,6 +724,80 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(const unsigned long
     write_result(keys, m, k, q, outD, outI, pos_offset);
 }
 
+// re-score slice `blockIdx.x` of query `blockIdx.y`'s survivors in fp32: key(approx, pos) -> key(exact, pos), in place.
+// Same per-row arithmetic as the fused kernel (one wave per row, one explicit fma chain): a row's score does not depend on
+// which kernel, slice or slot computed it.
+__global__ __launch_bounds__(256) void finalize_rescore_kernel(unsigned long long* cand, int cap, const int* m_in,
+                                                               const float* X, long long ldx, int d, const float* Q,
+                                                               long long ldq) {
+    __shared__ __attribute__((aligned(16))) float qv[2048];
+    const int q = blockIdx.y, m = m_in[q];
+    if (m <= 0) return;
+    const int per = (m + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = lo + per < m ? lo + per : m;
+    if (lo >= hi) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < d; i += 256) qv[i] = Q[(long long)q * ldq + i];
+    __syncthreads();
+    unsigned long long* keys = cand + (long long)q * cap;
+    const int d4 = d >> 2;
+    constexpr int RU = 16, NW = 4;
+    for (int i0 = lo + w; i0 < hi; i0 += NW * RU) {
+        float a[RU];
+        uint32_t pos[RU];
+        const f32x4* xr[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int i = i0 + NW * u;
+            a[u] = 0.f;
+            pos[u] = key_pos(keys[i < hi ? i : i0]);
+            xr[u] = reinterpret_cast<const f32x4*>(X + (long long)pos[u] * ldx);
+        }
+        for (int cc = lane; cc < d4; cc += 64) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * cc]);
+            f32x4 x[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) x[u] = xr[u][cc];
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+                a[u] = __builtin_fmaf(x[u][3], y[3], __builtin_fmaf(x[u][2], y[2], __builtin_fmaf(x[u][1], y[1],
+                                      __builtin_fmaf(x[u][0], y[0], a[u]))));
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            float v = a[u];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int i = i0 + NW * u;
+            if (lane == 0 && i < hi) keys[i] = (v == v) ? make_key(v, pos[u]) : 0ull;
+        }
+    }
+}
+
+// sort the re-scored survivors, certify (rows outside the list have exact < tau + eps), write
+__global__ __launch_bounds__(512) void finalize_sort_kernel(const unsigned long long* cand, const int* cnt, int cap, int k,
+                                                            long long nrows, const float* tau, const int* m_in,
+                                                            const float* eps_in, int* fail, float* outD, long long* outI,
+                                                            long long pos_offset) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int m = m_in[q];
+    if (m <= 0) return;                                       // given up (or nothing to do) in the select kernel
+    const int need = (int)(nrows < k ? nrows : k);
+    int P2 = 2;
+    while (P2 < m) P2 <<= 1;
+    for (int i = tid; i < P2; i += 512) keys[i] = i < m ? cand[(long long)q * cap + i] : 0ull;
+    __syncthreads();
+    bitonic_desc(keys, P2);
+    const unsigned long long kth = keys[need - 1];
+    const bool all_rows = (long long)cnt[q] >= nrows;
+    if (!all_rows && !(kth != 0ull && key_score(kth) >= tau[q] + eps_in[q])) {
+        if (tid == 0) { fail[q] = 1; atomicAdd(&fail[gridDim.x], 1); }
+        return;
+    }
+    write_result(keys, m, k, q, outD, outI, pos_offset);
+}
+
 __global__ void fill_f32_kernel(float* p, long long n, float v) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -713,7 +809,7 @@ struct SearchPlan {
     long long gstride;       // rows between sample blocks
     int rank;                // r
     int nslices;             // fix-up slices
-    size_t off_tau, off_cnt, off_fail, off_cand, off_sample, off_fix, off_q16, bytes;
+    size_t off_tau, off_cnt, off_fail, off_cand, off_sample, off_fix, off_q16, off_m, off_eps, bytes;
 };
 
 // dim16 > 0: the mixed-precision search, which also keeps a bf16 copy of the queries in the workspace
@@ -746,6 +842,8 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
     pl.off_sample = o; o = align_up(o + (size_t)nq * (size_t)pl.n_sample * 4, 256);
     pl.off_fix = o;    o = align_up(o + (size_t)nq * pl.nslices * k * 8, 256);
     pl.off_q16 = o;    o = align_up(o + (size_t)nq * (size_t)dim16 * 2, 256);
+    pl.off_m = o;      o = align_up(o + (size_t)(dim16 ? nq : 0) * 4, 256);      // split finalize: survivors per query, eps per query
+    pl.off_eps = o;    o = align_up(o + (size_t)(dim16 ? nq : 0) * 4, 256);
     pl.bytes = o;
     return 0;
 }
@@ -955,8 +1053,12 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     const size_t fin_lds = (size_t)CAND_CAP * 8 + (size_t)dim * 4;
     static PerDeviceOnce attr_done;
     if (attr_done.pending()) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_mixed_kernel),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_mixed_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_mixed_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_sort_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_merge_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
         attr_done.mark();
@@ -966,9 +1068,26 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     const float* tau = reinterpret_cast<const float*>(ws + pl.off_tau);
     {
         ProfScope prof("search_finalize_mixed", 0.0, 0.0, st);
-        hipLaunchKernelGGL(finalize_mixed_kernel, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, cnt, CAND_CAP, k,
-                           (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries,
-                           (long long)ld_queries, fail, out_scores, (long long*)out_pos, (long long)pos_offset);
+        if (nq <= SPLIT_MAX_NQ) {
+            int* m_q = reinterpret_cast<int*>(ws + pl.off_m);
+            float* eps_q = reinterpret_cast<float*>(ws + pl.off_eps);
+            int slices = (int)(1024 / nq);                          // ~1000 re-score blocks in all
+            slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
+            hipLaunchKernelGGL(finalize_mixed_kernel<true>, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, cnt, CAND_CAP, k,
+                               (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries,
+                               (long long)ld_queries, fail, out_scores, (long long*)out_pos, (long long)pos_offset, m_q, eps_q);
+            hipLaunchKernelGGL(finalize_rescore_kernel, dim3((unsigned)slices, (unsigned)nq), dim3(256), 0, st, cand, CAND_CAP,
+                               (const int*)m_q, corpus, (long long)ld_corpus, dim, queries, (long long)ld_queries);
+            hipLaunchKernelGGL(finalize_sort_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st,
+                               (const unsigned long long*)cand, (const int*)cnt, CAND_CAP, k, (long long)nrows, tau,
+                               (const int*)m_q, (const float*)eps_q, fail, out_scores, (long long*)out_pos,
+                               (long long)pos_offset);
+        } else {
+            hipLaunchKernelGGL(finalize_mixed_kernel<false>, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, cnt, CAND_CAP, k,
+                               (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries,
+                               (long long)ld_queries, fail, out_scores, (long long*)out_pos, (long long)pos_offset,
+                               (int*)nullptr, (float*)nullptr);
+        }
     }
     ProfScope prof_fix("search_fixup", 0.0, 0.0, st);
     hipLaunchKernelGGL(fixup_scan_kernel, dim3((unsigned)(pl.nslices * nq)), dim3(512), 0, st, corpus,

@@ -19,9 +19,13 @@ q = q / q.norm(dim=1, keepdim=True)
 for _ in range(3):
     idx.search_device(q, 500, normalize=False)
 torch.cuda.synchronize()
+from amdrec import _lib
+_lib.profile_enable(True)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
     idx.search_device(q, 500, normalize=False)
 e1.record(); torch.cuda.synchronize()
-print(f"B={B} prefilter={pref} ms/search={e0.elapsed_time(e1) / reps:.4f}")
+prof = _lib.profile_report()
+parts = " ".join(f"{k.replace('search_', '')}={v['total_ms'] / v['launches']:.4f}" for k, v in sorted(prof.items()) if v["launches"])
+print(f"B={B} prefilter={pref} lib={os.path.basename(_lib.LIB_PATH)} ms/search={e0.elapsed_time(e1) / reps:.4f}  {parts}")
