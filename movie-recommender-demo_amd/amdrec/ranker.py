@@ -88,7 +88,10 @@ class TransformerRanker(nn.Module):
         #           architectures the row-owner kernel is not written for)
         #  "fp32"   fp32 MFMA everywhere
         self.gemm_engine = "f16x3"
-        self.x3_min_rows = self.SMALL_ROWS + 1       # tests set 1 to drive small batches through the row-owner kernel
+        # smallest pass that takes the row-owner kernel.  1 = every batch: one launch (~0.35 ms per 128-row round, bound by
+        # one CU's weight-stream rate) matches the ~25 small launches of the fp32 path at a single request (0.60 ms end to
+        # end either way) and beats it from 2 users up (B = 16: 0.65 vs 0.79 ms; tools/latency_by_engine.py)
+        self.x3_min_rows = 1
         self.x3_variant = 16                          # 16: rowowner16.hpp (two waves per SIMD, default: 15 % faster); 32: rowowner.hpp
 
     ENGINES = ("f16x3", "bf16x6", "fp32")
