@@ -49,11 +49,13 @@ int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld_corpus, in
 /* Mixed-precision form of the same search (same result contract: the exact fp32 top-k).  The sample and filter
  * passes read `corpus_bf16`, a bf16 (round-to-nearest) copy of the corpus made by amdrec_bf16_rows, with the bf16
  * MFMA; candidates are re-scored in fp32 from `corpus` and the result is certified against the error bound
- * eps = (2^-7 + 2^-16 + 2*dim*2^-24) * |query| * max_norm[0]  (bf16 unit roundoff 2^-8 on both operands)  (max_norm: device float = the largest row norm of the corpus, as
- * accumulated by amdrec_bf16_rows); uncertified queries take the exact fp32 fix-up scan.  dim % 8 == 0.
+ * eps = ||dq|| (M + D) + ||q|| D + 2 dim 2^-24 ||q|| (M + D),  dq = bf16(q) - q,  M = max_norm[0] = the largest row norm
+ * and D = max_norm[1] = the largest row rounding-error norm ||x - bf16(x)|| of the corpus (max_norm: device float[2],
+ * accumulated by amdrec_bf16_rows; at worst eps = (2^-7 + 2^-16) ||q|| M, the both-operands-half-an-ulp-off case);
+ * uncertified queries take the exact fp32 fix-up scan.  dim % 8 == 0.
  * Turns the filter pass from fp32-MFMA-bound into memory-bound (half the bytes, 16x the MFMA rate). */
 int amdrec_bf16_rows(const float* x, int64_t rows, int64_t ld, int dim, uint16_t* out /*[rows][ld_out] bf16*/,
-                     int64_t ld_out, float* max_norm /*device, in/out (atomic max), may be NULL*/, void* stream);
+                     int64_t ld_out, float* max_norm /*device float[2], in/out (atomic max), may be NULL*/, void* stream);
 int amdrec_flat_search_mixed_workspace(int64_t nq, int64_t nrows, int k, int dim, size_t* bytes /*host*/);
 int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int64_t ld_corpus, int dim,
                              const uint16_t* corpus_bf16, int64_t ld_bf16, const float* max_norm,

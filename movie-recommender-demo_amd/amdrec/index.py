@@ -113,7 +113,7 @@ class FAISSIndex:
         # bf16 shadow of the corpus + its largest row norm (the mixed search's error bound)
         self._mixed = self.index_type == "Flat" and self.prefilter == "bf16" and self.dimension % 8 == 0
         self._xb16 = torch.empty((0, self.dimension), dtype=torch.bfloat16, device=self.device)
-        self._maxnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._maxnorm = torch.zeros(2, dtype=torch.float32, device=self.device)     # [max row norm, max row rounding-error norm]
         self._identity = True          # ids == arange(n): remap is the identity
         self._host_ids: Optional[list] = None   # only for non-integer ids
         self._trained = self.index_type == "Flat"

@@ -19,9 +19,9 @@
 // Mixed-precision variant (amdrec_flat_search_mixed): passes 1-3 run on a bf16 copy of the corpus and of the
 // queries with v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, half the HBM bytes), which turns the filter from
 // MFMA-bound into memory-bound; the result stays the exact fp32 one because
-//   * eps_q = EPS_REL * |q| * max_row|x| bounds |approx - exact| for every row (bf16 round-to-nearest of both
-//     operands: bf16 keeps 8 significant bits, unit roundoff u = 2^-8 each, so a product is off by at most
-//     2u + u^2 = 0.00783 of |q_i x_i|; Cauchy-Schwarz over the row; plus the fp32 accumulation slack),
+//   * eps_q = ||dq|| (M + D) + ||q|| D bounds |approx - exact| for every row, from the MEASURED rounding errors of the
+//     query (dq) and of the corpus (D = max row error norm, M = max row norm; see eps_bound below): at worst the classical
+//     (2u + u^2) |q| |x| with u = 2^-8, ~4x smaller on real data; plus the fp32 accumulation slack,
 //   * finalize radix-selects a_k = the k-th largest approximate score, keeps the candidates with approx >= a_k - 2 eps
 //     (anything below is beaten by k rows), RE-SCORES them in fp32 from the fp32 corpus and sorts them,
 //   * and certifies: every row outside the list has approx < tau, i.e. exact < tau + eps; if the k-th re-scored
@@ -547,15 +547,16 @@ static hipError_t launch_scan(const uint16_t* X16, long long ld16, long long nro
     return hipGetLastError();
 }
 
-// fp32 rows -> bf16 rows (round to nearest even, NaN kept), one wave per row; optionally the maximum row norm
-// (atomic max over the float bits: norms are >= 0 so the unsigned order is the float order; NaN/inf propagate
+// fp32 rows -> bf16 rows (round to nearest even, NaN kept), one wave per row; optionally max_norm[0] = the maximum row norm
+// and max_norm[1] = the maximum ROUNDING-ERROR norm max_r ||x_r - bf16(x_r)||_2, the two corpus-side terms of the search's
+// error bound (atomic max over the float bits: norms are >= 0 so the unsigned order is the float order; NaN/inf propagate
 // and make every certificate fail -> exact fix-up path).
 __global__ __launch_bounds__(256) void bf16_rows_kernel(const float* x, long long rows, long long ld, int d,
                                                         uint16_t* out, long long ld_out, float* max_norm) {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
-    float ss = 0.f;
+    float ss = 0.f, ds = 0.f;
     for (int c = lane; c < (d >> 2); c += 64) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + 4 * c);
         uint32_t h[4];
@@ -564,23 +565,37 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const float* x, long lon
             const uint32_t u = __float_as_uint(v[e]);
             h[e] = (v[e] != v[e]) ? 0x7fc0u : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
             ss += v[e] * v[e];
+            const float dv = v[e] - __uint_as_float(h[e] << 16);       // exact: the rounding error of this component
+            ds += dv * dv;
         }
         uint2 pk{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
         *reinterpret_cast<uint2*>(out + r * ld_out + 4 * c) = pk;
     }
     if (max_norm) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(max_norm), __float_as_uint(sqrtf(ss)));
+        for (int o = 32; o > 0; o >>= 1) {
+            ss += __shfl_xor(ss, o, 64);
+            ds += __shfl_xor(ds, o, 64);
+        }
+        if (lane == 0) {
+            atomicMax(reinterpret_cast<unsigned int*>(max_norm), __float_as_uint(sqrtf(ss)));
+            // rounded UP a little: the sum above is itself an fp32 evaluation
+            atomicMax(reinterpret_cast<unsigned int*>(max_norm) + 1, __float_as_uint(sqrtf(ds) * 1.0001f));
+        }
     }
 }
 
-// |approx - exact| <= EPS_REL(d) * |q| * max|x|: bf16 has 8 significant bits, so round-to-nearest of an operand is a
-// relative error of at most u = 2^-8; both operands rounded: (1 + u)^2 - 1 = 2u + u^2 = 0.0078278 per product, rounded
-// up, and sum_i |q_i x_i| <= |q| |x| (Cauchy-Schwarz); plus 2 d 2^-24 for the two fp32 accumulations being compared.
-// (Round 1 used u = 2^-9, half the true bound: tests/test_search_gpu.py::test_mixed_worst_case_rounding holds the
-// input that exceeds that value.)
-__device__ __forceinline__ float eps_rel(int d) { return 0.00783f + (float)d * 1.2e-7f; }
+// Error bound of the bf16 pass, from MEASURED rounding errors (rigorous, and ~4x tighter than the worst case on real data):
+// with q~ = bf16(q), x~ = bf16(x), dq = q~ - q, dx = x~ - x:   q~.x~ - q.x = dq.x~ + q.dx   (an identity), hence
+//   |approx - exact| <= ||dq|| ||x~|| + ||q|| ||dx|| <= ||dq|| (M + D) + ||q|| D,    M = max_r ||x_r||, D = max_r ||dx_r||
+// (M, D accumulated by amdrec_bf16_rows when the shadow is written; ||dq|| computed here from the query itself), plus
+// 2 d 2^-24 ||q|| (M + D) for the two fp32 accumulations being compared.  The worst case of this bound is the classical
+// (2u + u^2) ||q|| M with u = 2^-8 (every component half an ulp off: tests/test_search_gpu.py::
+// test_mixed_worst_case_rounding, where round 1's u = 2^-9 constant returned a wrong top-k); on random unit vectors
+// ||dq|| ~ ||dx|| ~ 0.0008, i.e. eps ~ 0.0018 instead of 0.0078: half as many candidates survive the prune and are re-scored.
+__device__ __forceinline__ float eps_bound(float qn, float dqn, float M, float D, int d) {
+    return (dqn * (M + D) + qn * D) * 1.0001f + (float)d * 1.2e-7f * qn * (M + D);
+}
 
 // step 4 of the mixed-precision search: select a_k -> prune -> fp32 re-score -> exact sort -> certificate.
 // The candidate keys (<= 16 per thread) stay in registers for the selection: a 3-pass radix select of the k-th
@@ -602,7 +617,7 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long*
     float* qv = reinterpret_cast<float*>(keys + cap);
     __shared__ int hist[2048];
     __shared__ int scratch[514];
-    __shared__ float red[8];
+    __shared__ float red[16];
     __shared__ int m_sh;
     constexpr int PER = CAND_CAP / 512;                       // keys per thread (cap == CAND_CAP)
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -616,15 +631,21 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long*
         }
     };
     if (c < need || c > cap) { give_up(); return; }
-    float ss = 0.f;
+    float ss = 0.f, ds = 0.f;
     for (int i = tid; i < d; i += 512) {
         const float v = Q[(long long)q * ldq + i];
         qv[i] = v;
         ss += v * v;
+        const uint32_t u = __float_as_uint(v);                    // the same rounding as bf16_rows_kernel applied to the query
+        const float dv = v - __uint_as_float(((u + 0x7fffu + ((u >> 16) & 1u)) >> 16) << 16);
+        ds += dv * dv;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    if (lane == 0) red[w] = ss;
+    for (int o = 32; o > 0; o >>= 1) {
+        ss += __shfl_xor(ss, o, 64);
+        ds += __shfl_xor(ds, o, 64);
+    }
+    if (lane == 0) { red[w] = ss; red[8 + w] = ds; }
     if (tid == 0) m_sh = 0;
     unsigned long long mine[PER];
 #pragma unroll
@@ -633,10 +654,10 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long*
         mine[j] = (i < c) ? cand[(long long)q * cap + i] : 0ull;
     }
     __syncthreads();
-    float qn = 0.f;
+    float qn = 0.f, dqn = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) qn += red[i];
-    const float eps = eps_rel(d) * sqrtf(qn) * max_norm[0];
+    for (int i = 0; i < 8; ++i) { qn += red[i]; dqn += red[8 + i]; }
+    const float eps = eps_bound(sqrtf(qn), sqrtf(dqn) * 1.0001f, max_norm[0], max_norm[1], d);
     if (!(eps < INFINITY)) { give_up(); return; }            // NaN / inf norms: exact path (block-uniform)
     if (need == 0) {
         write_result(keys, 0, k, q, outD, outI, pos_offset);

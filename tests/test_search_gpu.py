@@ -166,7 +166,9 @@ def test_bf16_shadow_rows_and_max_norm():
     idx.add(xb[3000:])                                              # growth + append keep the shadow in step
     x = idx._xb[:5000]
     assert torch.equal(idx._xb16[:5000].view(torch.int16), x.to(torch.bfloat16).view(torch.int16))
-    assert abs(idx._maxnorm.item() - x.norm(dim=1).max().item()) <= 1e-6
+    assert abs(idx._maxnorm[0].item() - x.norm(dim=1).max().item()) <= 1e-6
+    dmax = (x - x.to(torch.bfloat16).float()).norm(dim=1).max().item()               # largest rounding-error norm of a row
+    assert dmax <= idx._maxnorm[1].item() <= dmax * 1.001
 
 
 def test_mixed_search_is_exact_on_unnormalised_rows_and_clustered_scores():
@@ -183,7 +185,7 @@ def test_mixed_search_is_exact_on_unnormalised_rows_and_clustered_scores():
     xb[1000:1300] = xq[0] / np.linalg.norm(xq[0]) * 3.0 + rng.standard_normal((300, d)).astype(np.float32) * 1e-5
     X = torch.from_numpy(xb).cuda()
     X16 = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
-    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+    mx = torch.zeros(2, dtype=torch.float32, device="cuda")
     lib = _lib.load()
     _lib.check(lib.amdrec_bf16_rows(_lib.ptr(X), n, d, d, _lib.ptr(X16), d, _lib.ptr(mx), _lib.stream_ptr(X.device)))
     Q = torch.from_numpy(xq).cuda()
@@ -287,7 +289,7 @@ def test_mixed_worst_case_rounding():
     xq = np.stack([np.full(d, a, dtype=np.float32), _mk(1, d, 5)[0]])
     X = torch.from_numpy(xb).cuda()
     X16 = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
-    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+    mx = torch.zeros(2, dtype=torch.float32, device="cuda")
     lib = _lib.load()
     _lib.check(lib.amdrec_bf16_rows(_lib.ptr(X), n, d, d, _lib.ptr(X16), d, _lib.ptr(mx), _lib.stream_ptr(X.device)))
     Q = torch.from_numpy(xq).cuda()
