@@ -171,8 +171,8 @@ def main():
                          "clustered one (default for ivf: an inverted file needs structure to exploit)")
     ap.add_argument("--ads", type=int, default=N_ADS, help="corpus size (configs[3]: 10000000)")
     ap.add_argument("--index", choices=["flat", "ivf"], default="flat", help="configs[4]: ivf")
-    ap.add_argument("--nlist", type=int, default=4096, help="IVF lists over the WHOLE corpus (split over the ranks)")
-    ap.add_argument("--nprobe", type=int, default=64, help="IVF probes over the whole corpus (split over the ranks)")
+    ap.add_argument("--nlist", type=int, default=4096, help="IVF lists of the coarse quantizer shared by all ranks (whole corpus)")
+    ap.add_argument("--nprobe", type=int, default=64, help="IVF probes per query (every rank scans its slice of each probed list)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
