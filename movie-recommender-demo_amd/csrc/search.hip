@@ -88,13 +88,14 @@ struct EpiFilter {
     static constexpr double out_bytes_per_elem = 0.0;
     static constexpr size_t lds_bytes(int) { return 16 + (size_t)HIT_CAP * 12; }
     const float* tau;            // [nq]
-    unsigned long long* cand;    // [nq][cap]
+    unsigned long long* cand;    // [nq][stride], the first cap of each block are used
     int* cnt;                    // [nq]
     int cap, nq;
     long long nrows;
+    long long stride;
     __device__ __forceinline__ void append(int q, unsigned long long key) const {
         const int pos = atomicAdd(&cnt[q], 1);
-        if (pos < cap) cand[(long long)q * cap + pos] = key;
+        if (pos < cap) cand[(long long)q * stride + pos] = key;
     }
     template <class A>
     __device__ void operator()(A& acc, float* smem) const {
@@ -312,15 +313,17 @@ __global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, con
 // latency-bound at ~14 % of HBM.  Here the roles are fixed for the whole launch instead:
 //  * one 8-wave workgroup per CU; wave w owns queries [64 w, 64 w + 64) of the block's 512-query group and keeps
 //    their bf16 fragments for the WHOLE K extent in registers (2 x KS x 4 VGPRs = 128 at dim 256): queries are read
-//    once per launch, never staged through LDS;
+//    once per launch, never staged through LDS (groups of <= 256 queries: the spare waves share the tile's rows);
 //  * the corpus streams through a two-deep LDS ring of 128-row full-K tiles (64 KB at dim 256) filled by LDS-DMA
 //    (global_load_lds, 16 B per lane, source-side XOR swizzle so the fragment reads are conflict-free); the next tile
 //    is in flight during the MFMAs on the current one - one barrier per tile;
 //  * every wave multiplies the same 32 corpus rows at a time (one A fragment per k16 step, read from LDS four steps
 //    ahead) with its own 64 queries: 2 accumulator tiles, v_mfma_f32_32x32x16_bf16, then compares against tau_q;
 //  * hits go to a wave-private LDS list without atomics (ballot + lane prefix; the wave's count lives in an SGPR);
-//    the wave appends them to the global candidate lists one tile later: the returning global atomics are issued
-//    before the next tile's MFMAs and their results consumed after, so their latency is never exposed.
+//    one tile later the wave files them in the workgroup's OWN segment of each query's candidate block (slot-major,
+//    CAND_CAP / workgroups slots per query; the slot comes from an LDS counter) - no global atomic, and the key stores
+//    go out before the next tile's DMA so the in-order vmcnt wait for that DMA never waits for them.  A full segment
+//    spills to the query's overflow block through a global counter; finalize_mixed_kernel reads the segments in place.
 // Each corpus byte is read from HBM once per 512 queries; waves whose queries lie beyond nq skip their MFMAs, so a
 // small batch runs at the HBM rate and a full one at the bf16 MFMA rate.
 constexpr int SCAN_ROWS = 128;          // corpus rows per LDS tile
@@ -339,7 +342,7 @@ template <int KS>                       // KS = dim / 16 in {2, 4, 8, 16}
 __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __restrict__ X16, long long ld16,
                                                              long long nrows, const uint16_t* __restrict__ Q16, int nq,
                                                              const float* __restrict__ tau, unsigned long long* cand,
-                                                             int* cnt, int cap, int nx) {
+                                                             int* segcnt, int* ocnt, int seg_cap, int nx) {
     constexpr int CPR = 2 * KS;                                  // 16-byte chunks per row
     constexpr int FM = CPR < 16 ? CPR - 1 : 15;                  // swizzle mask
     constexpr int FS = CPR >= 16 ? 0 : (CPR == 8 ? 1 : 2);       // swizzle row shift
@@ -353,10 +356,21 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                        // scalar: wave-uniform branches below
     unsigned char* hitbase = lds + 2 * TILE_CHUNKS * 16 + w * (SCAN_WHITS * 12);   // this wave's list 0; list 1 is
     constexpr int LIST_STRIDE = 8 * SCAN_WHITS * 12;                               // LIST_STRIDE bytes further
+    int* lcnt = reinterpret_cast<int*>(lds + 2 * TILE_CHUNKS * 16 + SCAN_HIT_BYTES);   // [SCAN_QGROUP] hits per query, this WG
+    lcnt[tid] = 0;                                                                 // (before the first DMA is in flight)
     const int frow = lane & 31, fh = lane >> 5;
     const int bx = blockIdx.x % nx, by = blockIdx.x / nx;
-    const int q0 = by * SCAN_QGROUP + w * 64;
-    const bool active = q0 < nq;
+    // Work split inside the workgroup.  A full group gives every wave its own 64 queries and all 128 rows of a tile; a
+    // group with fewer queries would leave most waves idle and one or two waves with the whole tile's MFMAs, threshold
+    // scan and hit handling (measured: 0.205 ms at 128 queries against 0.117 with the split), so the waves without
+    // queries of their own take a share of the tile's ROWS instead: 1 / 2 / 4 / 8 query waves x up to four 32-row parts.
+    const int nqg = nq - by * SCAN_QGROUP < SCAN_QGROUP ? nq - by * SCAN_QGROUP : SCAN_QGROUP;
+    const int qsh = nqg <= 64 ? 0 : (nqg <= 128 ? 1 : (nqg <= 256 ? 2 : 3));       // log2 of the query waves
+    const int parts = qsh <= 1 ? 4 : (qsh == 2 ? 2 : 1);
+    const int part = w >> qsh;
+    const int q0 = by * SCAN_QGROUP + (w & ((1 << qsh) - 1)) * 64;
+    const bool active = q0 < nq && part < parts;
+    const int rq_begin = part * (4 / parts), rq_end = rq_begin + 4 / parts;
     const bool second = q0 + 32 < nq;                                              // second query tile has real queries
     const int ntiles = (int)((nrows + SCAN_ROWS - 1) / SCAN_ROWS);
     const int nrows_i = (int)nrows;                                                // < 2^31 (checked by the entry point)
@@ -405,9 +419,20 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
             }
         }
     };
+    // A hit goes to THIS workgroup's segment of the query's candidate block: the slot comes from an LDS counter, so the
+    // corpus pass issues no global atomic (a returning device-scope atomic per hit, and its store waited for at the end
+    // of the tile, cost 0.07-0.25 ms per pass: profiles/r02_scan_hit_cost.log).  A full segment spills to the query's
+    // overflow block through a global counter (large k, skewed data: rare).
+    const int qbase = by * SCAN_QGROUP;
     auto append = [&](int q, unsigned long long key) {
-        const int pos = atomicAdd(&cnt[q], 1);
-        if (pos < cap) cand[(long long)q * cap + pos] = key;
+        const int slot = atomicAdd(&lcnt[q - qbase], 1);
+        unsigned long long* blk = cand + (long long)q * (2 * CAND_CAP);
+        if (slot < seg_cap) {
+            blk[slot * nx + bx] = key;                     // slot-major: the used slots of all segments are the block's head
+        } else {
+            const int o = atomicAdd(&ocnt[q], 1);
+            if (o < CAND_CAP) blk[CAND_CAP + o] = key;
+        }
     };
     // 32 corpus rows (LDS image at `lb`, fragment k-offset swizzle G) x NJ query tiles: K loop with the A fragments
     // read AHEAD steps before their MFMA, then the threshold scan.  wcount = this wave's hits so far in this tile.
@@ -471,12 +496,11 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     int it = 0, wprev = 0;                                         // wprev: hits of the previous tile awaiting their append
     for (; t < ntiles; t += nx, ++it) {
         const int buf = it & 1;
-        // previous tile's hits, first 64: issue the position atomics now, consume them after this tile's MFMAs
+        // previous tile's hits: slots from the LDS counters, keys to the segment - issued BEFORE this tile's DMA so that the
+        // end-of-tile wait for the DMA (vmcnt counts in order) never waits for these stores
         const unsigned char* lprev = hitbase + (buf ^ 1) * LIST_STRIDE;
         const int npend = wprev < SCAN_WHITS ? wprev : SCAN_WHITS;
-        int pos = 0;
-        if (lane < npend) pos = atomicAdd(&cnt[reinterpret_cast<const int*>(lprev + SCAN_WHITS * 8)[lane]], 1);
-        for (int h = 64 + lane; h < npend; h += 64)                // more than 64 hits in one tile: rare
+        for (int h = lane; h < npend; h += 64)
             append(reinterpret_cast<const int*>(lprev + SCAN_WHITS * 8)[h],
                    reinterpret_cast<const unsigned long long*>(lprev)[h]);
         if (t + nx < ntiles) dma(t + nx, buf ^ 1);
@@ -493,7 +517,7 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
             using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>;
 #pragma unroll 1
-            for (int rq = 0; rq < SCAN_ROWS / 32; ++rq) {
+            for (int rq = rq_begin; rq < rq_end; ++rq) {
                 asm volatile("" : "+v"(G));
                 const int prow = t * SCAN_ROWS + rq * 32 + 4 * fh;
                 const unsigned char* lq = lb + rq * 32 * CPR * 16;
@@ -506,10 +530,6 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
                 }
             }
         }
-        if (lane < npend && lane < 64) {
-            const int q = reinterpret_cast<const int*>(lprev + SCAN_WHITS * 8)[lane];
-            if (pos < cap) cand[(long long)q * cap + pos] = reinterpret_cast<const unsigned long long*>(lprev)[lane];
-        }
         wprev = wcount;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of tile t+nx landed, my hit stores done
         __syncthreads();                 // tile t consumed by every wave, tile t+nx visible
@@ -519,13 +539,25 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     const int nlast = wprev < SCAN_WHITS ? wprev : SCAN_WHITS;
     for (int h = lane; h < nlast; h += 64)
         append(reinterpret_cast<const int*>(llast + SCAN_WHITS * 8)[h], reinterpret_cast<const unsigned long long*>(llast)[h]);
+    __syncthreads();
+    if (tid < nqg) segcnt[(long long)(qbase + tid) * nx + bx] = lcnt[tid];      // every (query, segment) count is written: no memset
+}
+
+// segments per query = workgroups per 512-query group of the streaming pass; each owns CAND_CAP / nseg candidate slots
+static inline int scan_segments(long long nrows, long long nq) {
+    const long long ntiles = (nrows + SCAN_ROWS - 1) / SCAN_ROWS;
+    const long long ny = (nq + SCAN_QGROUP - 1) / SCAN_QGROUP;
+    long long nx = 256 / ny;                       // one workgroup per CU
+    if (nx < 1) nx = 1;
+    if (nx > ntiles) nx = ntiles;
+    return (int)(nx < 1 ? 1 : nx);
 }
 
 template <int KS>
 static hipError_t launch_scan(const uint16_t* X16, long long ld16, long long nrows, const uint16_t* Q16, int nq,
-                              const float* tau, unsigned long long* cand, int* cnt, hipStream_t st) {
+                              const float* tau, unsigned long long* cand, int* segcnt, int* ocnt, hipStream_t st) {
     auto kern = scan_filter_kernel<KS>;
-    constexpr size_t lds_bytes = 2ull * SCAN_ROWS * 2 * KS * 16 + SCAN_HIT_BYTES;
+    constexpr size_t lds_bytes = 2ull * SCAN_ROWS * 2 * KS * 16 + SCAN_HIT_BYTES + SCAN_QGROUP * 4;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     static PerDeviceOnce attr_done;
     if (attr_done.pending()) {
@@ -534,16 +566,13 @@ static hipError_t launch_scan(const uint16_t* X16, long long ld16, long long nro
         if (e != hipSuccess) return e;
         attr_done.mark();
     }
-    const long long ntiles = (nrows + SCAN_ROWS - 1) / SCAN_ROWS;
     const int ny = (nq + SCAN_QGROUP - 1) / SCAN_QGROUP;
-    long long nx = 256 / ny;                       // one workgroup per CU
-    if (nx < 1) nx = 1;
-    if (nx > ntiles) nx = ntiles;
+    const int nx = scan_segments(nrows, nq);
     const int d = 16 * KS;
     ProfScope prof("search_filter_stream128x512_bf16", 2.0 * (double)nrows * (double)nq * d,
                    2.0 * ((double)nrows * d * ny + (double)nq * d), st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nx * ny)), dim3(512), lds_bytes, st, X16, ld16, nrows, Q16, nq, tau, cand, cnt,
-                       CAND_CAP, (int)nx);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nx * ny)), dim3(512), lds_bytes, st, X16, ld16, nrows, Q16, nq, tau, cand, segcnt,
+                       ocnt, CAND_CAP / nx, nx);
     return hipGetLastError();
 }
 
@@ -606,22 +635,28 @@ __device__ __forceinline__ float eps_bound(float qn, float dqn, float M, float D
 // ONE query over several workgroups (a single block re-scoring ~1200 random 1 KB rows is latency-bound: 83 us at B = 1)
 // and finalize_sort_kernel sorts and certifies.  Large batches keep the fused form: one block per query already fills the chip.
 constexpr int SPLIT_MAX_NQ = 128;
+// Candidate input: block q of `cand` (cstride keys) = nseg segments of seg_cap slots, slot-major (slot s of segment g at
+// s * nseg + g) [+ an overflow block at CAND_CAP when the streaming pass produced it]; segcnt[q][nseg] = hits each segment
+// saw (may exceed seg_cap: the excess went to the overflow block, ocnt[q] entries).  The generic GEMM pass writes one
+// segment (nseg = 1, seg_cap = CAND_CAP, no overflow).
 template <bool SPLIT>
-__global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long* cand, const int* cnt, int cap,
+__global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long* cand, long long cstride, const int* segcnt,
+                                                             int nseg, int seg_cap, const int* ocnt, int cap,
                                                              int k, long long nrows, const float* tau,
                                                              const float* max_norm, const float* X, long long ldx,
                                                              int d, const float* Q, long long ldq, int* fail,
                                                              float* outD, long long* outI, long long pos_offset,
-                                                             int* m_out, float* eps_out) {
+                                                             int* m_out, float* eps_out, int* c_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [cap] then qv[d]
     float* qv = reinterpret_cast<float*>(keys + cap);
     __shared__ int hist[2048];
     __shared__ int scratch[514];
     __shared__ float red[16];
     __shared__ int m_sh;
-    constexpr int PER = CAND_CAP / 512;                       // keys per thread (cap == CAND_CAP)
+    __shared__ int seg_n[256], tot_sh, lost_sh;
+    constexpr int PER = CAND_CAP / 512;                       // segment slots per thread (cap == CAND_CAP)
+    constexpr int OVP = 4;                                    // overflow keys per thread: up to 2048 per query
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int c = cnt[q];
     const int need = (int)(nrows < k ? nrows : k);
     auto give_up = [&]() {
         if (tid == 0) {
@@ -630,7 +665,31 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long*
             if (SPLIT) m_out[q] = -1;                             // the follow-up kernels skip this query
         }
     };
-    if (c < need || c > cap) { give_up(); return; }
+    // segment counts: valid slots per segment, their total, and the hits that did not fit
+    if (tid == 0) { tot_sh = 0; lost_sh = 0; }
+    __syncthreads();
+    int sv = 0, lost = 0;
+    if (tid < nseg) {
+        const int v = segcnt[(long long)q * nseg + tid];
+        sv = v < seg_cap ? v : seg_cap;
+        lost = v - sv;
+        seg_n[tid] = sv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sv += __shfl_xor(sv, o, 64);
+        lost += __shfl_xor(lost, o, 64);
+    }
+    if (lane == 0 && w * 64 < nseg) {
+        atomicAdd(&tot_sh, sv);
+        if (lost) atomicAdd(&lost_sh, lost);
+    }
+    const int oc = ocnt[q];
+    __syncthreads();
+    const int c = tot_sh + oc;
+    // every hit must be in a segment or in the overflow block, and the list must be usable (block-uniform tests)
+    if (lost_sh != oc || oc > 512 * OVP || c < need || c > cap) { give_up(); return; }
+    if (SPLIT && tid == 0) c_out[q] = c;
     float ss = 0.f, ds = 0.f;
     for (int i = tid; i < d; i += 512) {
         const float v = Q[(long long)q * ldq + i];
@@ -647,11 +706,26 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long*
     }
     if (lane == 0) { red[w] = ss; red[8 + w] = ds; }
     if (tid == 0) m_sh = 0;
-    unsigned long long mine[PER];
+    // the candidates stay where the pass put them: thread <- slots tid + 512 j of the segment area, validity from the
+    // segment's count (an empty slot is key 0, which no hit can be: its score would have to be NaN)
+    const unsigned long long* blk = cand + (long long)q * cstride;
+    const int nslots = nseg * seg_cap;
+    const int seg_shift = (nseg & (nseg - 1)) == 0 ? 31 - __builtin_clz((unsigned)nseg) : -1;      // nseg a power of two
+    unsigned long long mine[PER + OVP];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
+        const int s_ = tid + 512 * j;                          // slot-major: element (slot, segment) at slot * nseg + segment
+        bool ok = false;
+        if (s_ < nslots) {
+            const int slot = seg_shift >= 0 ? s_ >> seg_shift : s_ / nseg;
+            ok = slot < seg_n[s_ - slot * nseg];
+        }
+        mine[j] = ok ? blk[s_] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < OVP; ++j) {
         const int i = tid + 512 * j;
-        mine[j] = (i < c) ? cand[(long long)q * cap + i] : 0ull;
+        mine[PER + j] = (i < oc) ? blk[CAND_CAP + i] : 0ull;
     }
     __syncthreads();
     float qn = 0.f, dqn = 0.f;
@@ -675,9 +749,9 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long*
         __syncthreads();
         const uint32_t bm = (1u << nbits[pass]) - 1u;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
+        for (int j = 0; j < PER + OVP; ++j) {
             const uint32_t u = (uint32_t)(mine[j] >> 32);
-            if (tid + 512 * j < c && (u & pmask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & bm], 1);
+            if (mine[j] != 0ull && (u & pmask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & bm], 1);
         }
         __syncthreads();
         const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);      // always found: c >= need >= rr
@@ -687,12 +761,12 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long*
     // prune: a row with approx < a_k - 2 eps has exact < a_k - eps <= exact of each of the k best-by-approx rows
     const float cut = f32_from_orderable(prefix) - 2.f * eps;
 #pragma unroll
-    for (int j = 0; j < PER; ++j)
-        if (tid + 512 * j < c && key_score(mine[j]) >= cut) keys[atomicAdd(&m_sh, 1)] = mine[j];
+    for (int j = 0; j < PER + OVP; ++j)
+        if (mine[j] != 0ull && key_score(mine[j]) >= cut) keys[atomicAdd(&m_sh, 1)] = mine[j];
     __syncthreads();
     const int m = m_sh;                                       // need <= m <= c
     if constexpr (SPLIT) {                                    // publish: survivors overwrite the head of the candidate list
-        for (int i = tid; i < m; i += 512) cand[(long long)q * cap + i] = keys[i];     // (every thread read its share above)
+        for (int i = tid; i < m; i += 512) cand[(long long)q * cstride + i] = keys[i]; // (every thread read its share above)
         if (tid == 0) { m_out[q] = m; eps_out[q] = eps; }
         return;
     }
@@ -748,7 +822,7 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long*
 // re-score slice `blockIdx.x` of query `blockIdx.y`'s survivors in fp32: key(approx, pos) -> key(exact, pos), in place.
 // Same per-row arithmetic as the fused kernel (one wave per row, one explicit fma chain): a row's score does not depend on
 // which kernel, slice or slot computed it.
-__global__ __launch_bounds__(256) void finalize_rescore_kernel(unsigned long long* cand, int cap, const int* m_in,
+__global__ __launch_bounds__(256) void finalize_rescore_kernel(unsigned long long* cand, long long cap, const int* m_in,
                                                                const float* X, long long ldx, int d, const float* Q,
                                                                long long ldq) {
     __shared__ __attribute__((aligned(16))) float qv[2048];
@@ -760,7 +834,7 @@ __global__ __launch_bounds__(256) void finalize_rescore_kernel(unsigned long lon
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < d; i += 256) qv[i] = Q[(long long)q * ldq + i];
     __syncthreads();
-    unsigned long long* keys = cand + (long long)q * cap;
+    unsigned long long* keys = cand + (long long)q * cap;        // cap = keys between the queries' blocks
     const int d4 = d >> 2;
     constexpr int RU = 16, NW = 4;
     for (int i0 = lo + w; i0 < hi; i0 += NW * RU) {
@@ -796,7 +870,7 @@ __global__ __launch_bounds__(256) void finalize_rescore_kernel(unsigned long lon
 }
 
 // sort the re-scored survivors, certify (rows outside the list have exact < tau + eps), write
-__global__ __launch_bounds__(512) void finalize_sort_kernel(const unsigned long long* cand, const int* cnt, int cap, int k,
+__global__ __launch_bounds__(512) void finalize_sort_kernel(const unsigned long long* cand, const int* cnt, long long cap, int k,
                                                             long long nrows, const float* tau, const int* m_in,
                                                             const float* eps_in, int* fail, float* outD, long long* outI,
                                                             long long pos_offset) {
@@ -830,7 +904,7 @@ struct SearchPlan {
     long long gstride;       // rows between sample blocks
     int rank;                // r
     int nslices;             // fix-up slices
-    size_t off_tau, off_cnt, off_fail, off_cand, off_sample, off_fix, off_q16, off_m, off_eps, bytes;
+    size_t off_tau, off_cnt, off_ocnt, off_fail, off_segcnt, off_cand, off_sample, off_fix, off_q16, off_m, off_eps, bytes;
 };
 
 // dim16 > 0: the mixed-precision search, which also keeps a bf16 copy of the queries in the workspace
@@ -857,13 +931,15 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
     pl.nslices = ns < 1 ? 1 : (ns > 16 ? 16 : ns);
     size_t o = 0;
     pl.off_tau = o;    o = align_up(o + (size_t)nq * 4, 256);
-    pl.off_cnt = o;    o = align_up(o + (size_t)nq * 4, 256);
+    pl.off_cnt = o;    o = align_up(o + (size_t)nq * 4, 256);                   // cnt | ocnt | fail: one memset
+    pl.off_ocnt = o;   o = align_up(o + (size_t)nq * 4, 256);
     pl.off_fail = o;   o = align_up(o + (size_t)(nq + 1) * 4, 256);
-    pl.off_cand = o;   o = align_up(o + (size_t)nq * CAND_CAP * 8, 256);
+    pl.off_segcnt = o; o = align_up(o + (size_t)(dim16 ? nq : 0) * 256 * 4, 256);  // streaming pass: hits per (query, segment)
+    pl.off_cand = o;   o = align_up(o + (size_t)nq * CAND_CAP * 8 * (dim16 ? 2 : 1), 256);   // mixed: + overflow block
     pl.off_sample = o; o = align_up(o + (size_t)nq * (size_t)pl.n_sample * 4, 256);
     pl.off_fix = o;    o = align_up(o + (size_t)nq * pl.nslices * k * 8, 256);
     pl.off_q16 = o;    o = align_up(o + (size_t)nq * (size_t)dim16 * 2, 256);
-    pl.off_m = o;      o = align_up(o + (size_t)(dim16 ? nq : 0) * 4, 256);      // split finalize: survivors per query, eps per query
+    pl.off_m = o;      o = align_up(o + (size_t)(dim16 ? nq : 0) * 8, 256);      // split finalize: survivors | candidates per query, eps per query
     pl.off_eps = o;    o = align_up(o + (size_t)(dim16 ? nq : 0) * 4, 256);
     pl.bytes = o;
     return 0;
@@ -874,7 +950,7 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
 template <class S>
 static hipError_t run_passes(const float* X, long long ldx, long long nrows, int d, const float* Q, long long ldq,
                              int nq, const SearchPlan& pl, char* ws, hipStream_t st, int d_alg = 0,
-                             bool filter = true) {
+                             bool filter = true, long long cand_stride = CAND_CAP) {
     DenseRows lq{Q, nq, (int)ldq, d, 30, 1ll << 30};
     float* tau = reinterpret_cast<float*>(ws + pl.off_tau);
     int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
@@ -894,7 +970,7 @@ static hipError_t run_passes(const float* X, long long ldx, long long nrows, int
     }
     if (!filter) return hipGetLastError();
     DenseRows lp{X, nrows, (int)ldx, d, 30, 1ll << 30};
-    EpiFilter ef{tau, reinterpret_cast<unsigned long long*>(ws + pl.off_cand), cnt, CAND_CAP, nq, nrows};
+    EpiFilter ef{tau, reinterpret_cast<unsigned long long*>(ws + pl.off_cand), cnt, CAND_CAP, nq, nrows, cand_stride};
     return launch_gemm<S, false>(lp, lq, ef, d, nrows, nq, st, d_alg);
 }
 
@@ -1041,9 +1117,16 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     REQUIRE(((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
     char* ws = reinterpret_cast<char*>(workspace);
     int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
+    int* ocnt = reinterpret_cast<int*>(ws + pl.off_ocnt);
     int* fail = reinterpret_cast<int*>(ws + pl.off_fail);
-    // cnt[nq] and fail[nq + 1] are adjacent in the plan: one fill
+    // cnt[nq], ocnt[nq] and fail[nq + 1] are adjacent in the plan: one fill
     HIP_TRY(hipMemsetAsync(cnt, 0, (pl.off_fail - pl.off_cnt) + (size_t)(nq + 1) * 4, st));
+    constexpr long long CSTRIDE = 2 * CAND_CAP;
+    // corpus pass: the streaming kernel for the power-of-two dims it is instantiated for, else the generic tiles
+    const bool streaming = nrows > 0 && (dim == 32 || dim == 64 || dim == 128 || dim == 256);
+    const int nseg = streaming ? scan_segments(nrows, nq) : 1;
+    const int seg_cap = CAND_CAP / nseg;
+    const int* segcnt = streaming ? reinterpret_cast<int*>(ws + pl.off_segcnt) : cnt;
 
     if (nrows > 0) {
         uint16_t* q16 = reinterpret_cast<uint16_t*>(ws + pl.off_q16);
@@ -1054,20 +1137,19 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
         const float* Q = reinterpret_cast<const float*>(q16);
         const long long ldx = ld_bf16 / 2, ldq = dim / 2;
         const int dh = dim / 2;
-        // corpus pass: the streaming kernel for the power-of-two dims it is instantiated for, else the generic tiles
-        const bool stream = dim == 32 || dim == 64 || dim == 128 || dim == 256;
         hipError_t e;
-        if (nq > 64)       e = run_passes<Shape<2, 2, 4, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !stream);
-        else if (nq > 32)  e = run_passes<Shape<4, 1, 2, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !stream);
-        else               e = run_passes<Shape<4, 1, 2, 1, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !stream);
+        if (nq > 64)       e = run_passes<Shape<2, 2, 4, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !streaming, CSTRIDE);
+        else if (nq > 32)  e = run_passes<Shape<4, 1, 2, 2, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !streaming, CSTRIDE);
+        else               e = run_passes<Shape<4, 1, 2, 1, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !streaming, CSTRIDE);
         HIP_TRY(e);
-        if (stream) {
+        if (streaming) {
             const float* tau_ = reinterpret_cast<const float*>(ws + pl.off_tau);
             unsigned long long* cand_ = reinterpret_cast<unsigned long long*>(ws + pl.off_cand);
-            if (dim == 256)      e = launch_scan<16>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, cnt, st);
-            else if (dim == 128) e = launch_scan<8>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, cnt, st);
-            else if (dim == 64)  e = launch_scan<4>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, cnt, st);
-            else                 e = launch_scan<2>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, cnt, st);
+            int* sc_ = reinterpret_cast<int*>(ws + pl.off_segcnt);
+            if (dim == 256)      e = launch_scan<16>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, sc_, ocnt, st);
+            else if (dim == 128) e = launch_scan<8>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, sc_, ocnt, st);
+            else if (dim == 64)  e = launch_scan<4>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, sc_, ocnt, st);
+            else                 e = launch_scan<2>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, sc_, ocnt, st);
             HIP_TRY(e);
         }
     }
@@ -1094,20 +1176,22 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
             float* eps_q = reinterpret_cast<float*>(ws + pl.off_eps);
             int slices = (int)(1024 / nq);                          // ~1000 re-score blocks in all
             slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
-            hipLaunchKernelGGL(finalize_mixed_kernel<true>, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, cnt, CAND_CAP, k,
-                               (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries,
-                               (long long)ld_queries, fail, out_scores, (long long*)out_pos, (long long)pos_offset, m_q, eps_q);
-            hipLaunchKernelGGL(finalize_rescore_kernel, dim3((unsigned)slices, (unsigned)nq), dim3(256), 0, st, cand, CAND_CAP,
+            int* c_q = m_q + nq;
+            hipLaunchKernelGGL(finalize_mixed_kernel<true>, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, CSTRIDE, segcnt, nseg,
+                               seg_cap, (const int*)ocnt, CAND_CAP, k, (long long)nrows, tau, max_norm, corpus,
+                               (long long)ld_corpus, dim, queries, (long long)ld_queries, fail, out_scores,
+                               (long long*)out_pos, (long long)pos_offset, m_q, eps_q, c_q);
+            hipLaunchKernelGGL(finalize_rescore_kernel, dim3((unsigned)slices, (unsigned)nq), dim3(256), 0, st, cand, CSTRIDE,
                                (const int*)m_q, corpus, (long long)ld_corpus, dim, queries, (long long)ld_queries);
             hipLaunchKernelGGL(finalize_sort_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st,
-                               (const unsigned long long*)cand, (const int*)cnt, CAND_CAP, k, (long long)nrows, tau,
+                               (const unsigned long long*)cand, (const int*)c_q, CSTRIDE, k, (long long)nrows, tau,
                                (const int*)m_q, (const float*)eps_q, fail, out_scores, (long long*)out_pos,
                                (long long)pos_offset);
         } else {
-            hipLaunchKernelGGL(finalize_mixed_kernel<false>, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, cnt, CAND_CAP, k,
-                               (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries,
-                               (long long)ld_queries, fail, out_scores, (long long*)out_pos, (long long)pos_offset,
-                               (int*)nullptr, (float*)nullptr);
+            hipLaunchKernelGGL(finalize_mixed_kernel<false>, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, CSTRIDE, segcnt, nseg,
+                               seg_cap, (const int*)ocnt, CAND_CAP, k, (long long)nrows, tau, max_norm, corpus,
+                               (long long)ld_corpus, dim, queries, (long long)ld_queries, fail, out_scores,
+                               (long long*)out_pos, (long long)pos_offset, (int*)nullptr, (float*)nullptr, (int*)nullptr);
         }
     }
     ProfScope prof_fix("search_fixup", 0.0, 0.0, st);

@@ -322,3 +322,42 @@ def test_more_than_65535_queries_in_one_call():
     sub = np.r_[0:40, 65_500:65_560, 65_990:66_000]
     rD, rI = oracle.search.flat_ip_search(xb, xq[sub], 5)
     oracle.search.check_topk(rD, rI, D[sub], ids[sub], tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
+
+
+@pytest.mark.parametrize("hot_tiles,expect_fixup", [(3, False), (24, True)])
+def test_hits_concentrated_in_one_workgroups_segment(hot_tiles, expect_fixup):
+    """The streaming pass files a hit in the segment of the workgroup that found it (CAND_CAP / 256 = 32 slots per
+    query at this size); workgroup w owns the 128-row tiles w, w + 256, ...  Rows of `hot_tiles` tiles of ONE workgroup
+    are made near-copies of query 0, so that its segment overflows: a few hundred extra hits go through the overflow
+    block (exact result, no fix-up), more than 2048 make the query take the exact fix-up scan.  Query 1 is ordinary."""
+    from amdrec import _lib
+    from amdrec.index import flat_search_mixed
+    if _PREFILTER != "bf16":
+        pytest.skip("mixed engine only")
+    n, d, k = 256 * 128 * 26, 256, 500
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    X = torch.randn((n, d), generator=g, device="cuda")
+    X /= X.norm(dim=1, keepdim=True)
+    Q = X[:2].clone() + 0.05 * torch.randn((2, d), generator=g, device="cuda")
+    Q /= Q.norm(dim=1, keepdim=True)
+    for i in range(hot_tiles):
+        t = 5 + 256 * i
+        rows = Q[0][None, :] + 0.02 * torch.randn((128, d), generator=g, device="cuda")
+        X[t * 128:(t + 1) * 128] = rows / rows.norm(dim=1, keepdim=True)
+    X16 = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
+    mx = torch.zeros(2, dtype=torch.float32, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.amdrec_bf16_rows(_lib.ptr(X), n, d, d, _lib.ptr(X16), d, _lib.ptr(mx), _lib.stream_ptr(X.device)))
+    D = torch.empty((2, k), dtype=torch.float32, device="cuda")
+    I = torch.empty((2, k), dtype=torch.int64, device="cuda")
+    nfix = torch.zeros(1, dtype=torch.int32, device="cuda")
+    flat_search_mixed(X, X16, mx, n, Q, k, D, I, n_fixup=nfix)
+    xb, xq = X.cpu().numpy(), Q.cpu().numpy()
+    rD, rI = oracle.search.flat_ip_search(xb, xq, k, dtype=np.float64)
+    oracle.search.check_topk(rD, rI, D.cpu().numpy(), I.cpu().numpy(), tau=cases.TOPK_TAU, score_tol=2 * cases.SCORE_ATOL)
+    hot = set()
+    for i in range(hot_tiles):
+        hot |= set(range((5 + 256 * i) * 128, (5 + 256 * i + 1) * 128))
+    assert len(set(I[0].cpu().tolist()) & hot) >= min(k, len(hot)) - 1      # query 0's top-k IS the hot rows
+    assert (int(nfix.item()) >= 1) == expect_fixup
