@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--corpus", choices=["random", "clustered"], default=None,
                     help="synthetic corpus: randn unit rows (the reference benchmark's, default for flat) or a "
                          "clustered one (default for ivf: an inverted file needs structure to exploit)")
+    ap.add_argument("--full-lists", action="store_true",
+                    help="N > 1: every shard sends its full top-500 (default: short lists with a proof of exactness)")
     ap.add_argument("--ads", type=int, default=N_ADS, help="corpus size (configs[3]: 10000000)")
     ap.add_argument("--index", choices=["flat", "ivf"], default="flat", help="configs[4]: ivf")
     ap.add_argument("--nlist", type=int, default=4096, help="IVF lists of the coarse quantizer shared by all ranks (whole corpus)")
@@ -230,8 +232,10 @@ def main():
 
     if world > 1:
         from amdrec.sharded import ShardedRecommender
-        runner = ShardedRecommender(rec, rank, world, shard_offset=row0)
-        step = lambda: runner.recommend_device(uc, un, TOP_K, STAGE1_K)     # noqa: E731
+        runner = ShardedRecommender(rec, rank, world, shard_offset=row0, shard_k=None if args.full_lists else "auto")
+        # short per-shard lists (amdrec.sharded): the proof of exactness is a device counter checked outside the timed
+        # region (after the warm-up and again after the timed steps; the batch is the same every step)
+        step = lambda: runner.recommend_device(uc, un, TOP_K, STAGE1_K, verify=False)     # noqa: E731
     else:
         step = lambda: rec.recommend_device(uc, un, TOP_K, STAGE1_K)        # noqa: E731
 
@@ -242,6 +246,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    short_lists = None
+    if world > 1:
+        short_lists = {"list_k": runner.list_k(STAGE1_K), "k": STAGE1_K, "inexact_in_warmup": runner.inexact_count()}
+        if short_lists["inexact_in_warmup"]:                 # not provably exact on this corpus: full lists from here on
+            runner.shard_k = None
+            step()
     barrier()
     _lib.profile_enable(True)                # HIP events around every GEMM launch, on the launch stream
     # per-step HIP events on the launch stream (torch's current stream IS the stream every kernel is enqueued on,
@@ -258,6 +268,10 @@ def main():
     prof = _lib.profile_report()
     _lib.profile_enable(False)
     if world > 1:
+        short_lists["list_k_timed"] = runner.list_k(STAGE1_K)
+        short_lists["inexact_in_timed_steps"] = runner.inexact_count()
+        if short_lists["inexact_in_timed_steps"]:
+            raise SystemExit("a timed step was not provably exact with short shard lists: rerun with --full-lists")
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -336,7 +350,8 @@ def main():
                            + (f" nlist={args.nlist} nprobe={args.nprobe}" if args.index == "ivf" else ""),
                            "n_ads": n_ads, "dim": DIM, "users_per_step": B_global, "stage1_k": STAGE1_K,
                            "top_k": TOP_K, "corpus_rows_per_gpu": rows,
-                           "parallelism": f"corpus row-sharded x{world}, ranker data-parallel over users"},
+                           "parallelism": f"corpus row-sharded x{world}, ranker data-parallel over users",
+                           "shard_lists": short_lists},
                 "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "kernels": kernels, "search": search}
         print(json.dumps(line), flush=True)
     if args.sweep and rank == 0 and world == 1:

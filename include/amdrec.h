@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMDREC_ABI_VERSION 4
+#define AMDREC_ABI_VERSION 5
 #define AMDREC_MAX_K 2048
 
 int amdrec_abi_version(void);
@@ -118,6 +118,16 @@ int amdrec_ivf_kmeans_step(const float* x, int64_t rows, int64_t ld, int dim, fl
 int amdrec_topk_merge(const float* scores, const int32_t* pos, int n_lists, int64_t list_stride_bytes,
                       int64_t q0, int64_t nq, int k, float* out_scores /*[nq][k]*/,
                       int64_t* out_pos /*[nq][k]*/, void* stream);
+/* Same with SHORT lists: every shard sends only its best list_k <= k rows per query (each list is [nq_total][list_k]),
+ * which cuts a shard's exact re-scoring and the wire bytes by k / list_k.  The merged top-k is the exact global top-k iff
+ * no shard was cut off above the merged k-th score; *n_inexact (device int32, NOT reset: accumulates) is incremented for
+ * every query where that cannot be shown - a full list whose last score reaches the merged k-th score (ties included),
+ * or fewer than k merged entries while some list is full.  The caller repeats such a batch with list_k = k
+ * (amdrec.sharded.ShardedRecommender does).  n_lists*list_k <= 16384. */
+int amdrec_topk_merge_partial(const float* scores, const int32_t* pos, int n_lists, int list_k,
+                              int64_t list_stride_bytes, int64_t q0, int64_t nq, int k,
+                              float* out_scores /*[nq][k]*/, int64_t* out_pos /*[nq][k]*/,
+                              int32_t* n_inexact /*device*/, void* stream);
 
 /* ---- two-tower encoders (eval mode) ------------------------------------------------------
  * Replaces the ATen call chain of UserTower.forward / AdTower.forward

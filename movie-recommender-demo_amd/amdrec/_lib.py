@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AMDREC_LIB_PATH: developer override for A/B runs of two builds of the library in otherwise identical processes
 LIB_PATH = os.environ.get("AMDREC_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libamdrec.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_K = 2048
 
 
@@ -44,6 +44,7 @@ _SIGNATURES = {
     "amdrec_ivf_kmeans_workspace": [_i64, _i32, _i32, C.POINTER(_sz)],
     "amdrec_ivf_kmeans_step": [_fp, _i64, _i64, _i32, _fp, _i32, _i64, _vp, _sz, _vp],
     "amdrec_topk_merge": [_fp, _vp, _i32, _i64, _i64, _i64, _i32, _fp, _vp, _vp],
+    "amdrec_topk_merge_partial": [_fp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _fp, _vp, _vp, _vp],
     "amdrec_tower_workspace": [_vp, _i64, C.POINTER(_sz)],
     "amdrec_tower_forward": [_vp, _vp, _fp, _i64, _fp, _i64, _vp, _vp, _sz, _vp],
     "amdrec_ranker_workspace": [_vp, _i64, C.POINTER(_sz)],

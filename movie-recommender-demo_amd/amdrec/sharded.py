@@ -15,6 +15,12 @@ rows [offset_r, offset_r + n_r); weights and the ad-feature table are replicated
      order rule as the single-GPU search: the result is bit-identical to an unsharded search);
   4. rank r ranks its own users' candidates (data parallel) and selects their top-k.
 
+Short lists (``shard_k``): a randomly sharded corpus puts k/G +- sqrt(k/G) of a user's top-k rows on each shard, so a
+shard need not produce (re-score exactly, sort, send) its own top-k: it sends its best ``short_list_k(k, G)`` rows
+(128 instead of 500 at G = 8) and the merge PROVES the result exact - every shard's last sent score lies below the merged
+k-th score (``amdrec_topk_merge_partial``) - or counts the query as inexact, in which case the step is repeated with full
+lists and short lists are switched off for this recommender (a corpus sharded by topic defeats the premise).
+
 The compute steps go through an ``engine`` so that the orchestration (slicing, packing, the
 collective, offsets) can be exercised on CPU under gloo with a test engine; the default
 engine is the HIP one and refuses CPU tensors.
@@ -34,6 +40,16 @@ def user_slice(n_users: int, rank: int, world: int):
     per = (n_users + world - 1) // world
     q0 = min(rank * per, n_users)
     return q0, min(per, n_users - q0)
+
+
+def short_list_k(k: int, world: int) -> int:
+    """Per-shard list length for a randomly sharded corpus: mean k/G + 6 sigma of Binomial(k, 1/G) + 8, rounded up to
+    a multiple of 32; k itself when that saves less than a fifth (small worlds, small k)."""
+    if world <= 1:
+        return k
+    m = k / world
+    kq = int(-(-(m + 6.0 * (m * (1.0 - 1.0 / world)) ** 0.5 + 8.0) // 32) * 32)
+    return k if kq > 0.8 * k else kq
 
 
 def packed_layout(n_users: int, k: int):
@@ -56,15 +72,24 @@ class HipEngine:
                                                          pos_offset=self.shard_offset)
         return scores, pos
 
-    def merge(self, gathered: torch.Tensor, world: int, n_users: int, k: int, q0: int, nq: int):
+    def merge(self, gathered: torch.Tensor, world: int, n_users: int, k: int, q0: int, nq: int, k_out: Optional[int] = None,
+              inexact: Optional[torch.Tensor] = None):
+        """``world`` lists of ``k`` entries per user -> top ``k_out`` (default k).  With k < k_out (short lists) ``inexact``
+        (device int32[1]) is incremented per query whose result could not be proven exact."""
         lib = _lib.load()
+        k_out = k if k_out is None else k_out
         s_bytes, chunk = packed_layout(n_users, k)
         dev = gathered.device
-        out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
-        out_p = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        out_s = torch.empty((nq, k_out), dtype=torch.float32, device=dev)
+        out_p = torch.empty((nq, k_out), dtype=torch.int64, device=dev)
         base = gathered.data_ptr()
-        _lib.check(lib.amdrec_topk_merge(_lib.C.c_void_p(base), _lib.C.c_void_p(base + s_bytes), world, chunk,
-                                         q0, nq, k, _lib.ptr(out_s), _lib.ptr(out_p), _lib.stream_ptr(dev)))
+        if k_out == k:
+            _lib.check(lib.amdrec_topk_merge(_lib.C.c_void_p(base), _lib.C.c_void_p(base + s_bytes), world, chunk,
+                                             q0, nq, k, _lib.ptr(out_s), _lib.ptr(out_p), _lib.stream_ptr(dev)))
+        else:
+            _lib.check(lib.amdrec_topk_merge_partial(_lib.C.c_void_p(base), _lib.C.c_void_p(base + s_bytes), world, k, chunk,
+                                                     q0, nq, k_out, _lib.ptr(out_s), _lib.ptr(out_p), _lib.ptr(inexact),
+                                                     _lib.stream_ptr(dev)))
         return out_s, out_p
 
     def rank(self, uc, un, cand_pos, top_k):
@@ -119,23 +144,69 @@ def all_to_all_bytes(out: torch.Tensor, inp: torch.Tensor, group=None):
 
 class ShardedRecommender:
     def __init__(self, rec, rank: int, world: int, shard_offset: int, group: Optional[dist.ProcessGroup] = None,
-                 engine=None, exchange: str = "auto"):
+                 engine=None, exchange: str = "auto", shard_k="auto"):
         """``exchange``: "all_to_all" - every rank sends each peer only the candidate lists of THAT peer's users
         (B*k*8 bytes in and out per rank, independent of the world size; needs n_users % world == 0);
-        "all_gather" - every rank receives every list (world x as much); "auto" picks all_to_all when it applies."""
+        "all_gather" - every rank receives every list (world x as much); "auto" picks all_to_all when it applies.
+        ``shard_k``: entries per shard list - "auto" = ``short_list_k(stage1_k, world)``, an int, or None = stage1_k
+        (full lists, no proof needed)."""
         if exchange not in ("auto", "all_to_all", "all_gather"):
             raise ValueError("exchange must be 'auto', 'all_to_all' or 'all_gather'")
+        if not (shard_k is None or shard_k == "auto" or (isinstance(shard_k, int) and shard_k >= 1)):
+            raise ValueError("shard_k must be 'auto', None or a positive int")
         self.rank, self.world, self.group, self.exchange = rank, world, group, exchange
+        self.shard_k = shard_k
         self.engine = engine if engine is not None else HipEngine(rec, shard_offset)
+        self._inexact = None                 # device int32[1]: queries of THIS rank's users not proven exact, accumulated
+
+    def list_k(self, stage1_k: int) -> int:
+        if self.shard_k is None or self.world <= 1:
+            return stage1_k
+        kq = short_list_k(stage1_k, self.world) if self.shard_k == "auto" else min(int(self.shard_k), stage1_k)
+        return stage1_k if kq * self.world < stage1_k else kq
+
+    def inexact_count(self, reset: bool = True) -> int:
+        """Queries (over ALL ranks) whose short-list merge was not proven exact since the last reset: one small
+        all-reduce + a host read.  Collective: every rank must call it."""
+        if self._inexact is None:
+            return 0
+        t = self._inexact.clone()
+        if self.world > 1:
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t = h
+            else:
+                dist.all_reduce(t, group=self.group)
+        if reset:
+            self._inexact.zero_()
+        return int(t.item())
 
     @torch.no_grad()
-    def recommend_device(self, user_categorical, user_numerical, top_k: int = 10, stage1_k: int = 500):
+    def recommend_device(self, user_categorical, user_numerical, top_k: int = 10, stage1_k: int = 500,
+                         verify: bool = True):
         """Global user batch (identical on every rank) -> this rank's users' results:
-        dict(ad_ids [nq,top_k], scores [3,nq,top_k], user_offset q0, candidate_ids, candidate_scores)."""
-        uc, un = user_categorical, user_numerical
-        B, k = uc.shape[0], stage1_k
+        dict(ad_ids [nq,top_k], scores [3,nq,top_k], user_offset q0, candidate_ids, candidate_scores).
+        With short lists and ``verify`` (default) the proof of exactness is checked on the host before returning (one tiny
+        all-reduce + a device sync) and a failed batch is recomputed with full lists; ``verify=False`` leaves the check
+        to the caller (``inexact_count()``, e.g. once per reporting interval)."""
+        kq = self.list_k(stage1_k)
+        out = self._step(user_categorical, user_numerical, top_k, stage1_k, kq)
+        if kq < stage1_k and verify and self.inexact_count() > 0:
+            self.shard_k = None                                               # this corpus is not randomly sharded
+            out = self._step(user_categorical, user_numerical, top_k, stage1_k, stage1_k)
+        return out
+
+    def _step(self, uc, un, top_k: int, k_out: int, k: int):
+        """One exchange with lists of k entries per shard, merged to k_out candidates per user."""
+        B = uc.shape[0]
         scores, pos = self.engine.local_search(uc, un, k)                     # [B,k] each
         q0, nq = user_slice(B, self.rank, self.world)
+        inexact = None
+        if k < k_out:
+            if self._inexact is None:
+                self._inexact = torch.zeros(1, dtype=torch.int32, device=scores.device)
+            inexact = self._inexact
         if self.exchange == "all_to_all" and B % self.world:
             raise ValueError("exchange='all_to_all' needs n_users divisible by the world size")
         if self.exchange != "all_gather" and B % self.world == 0 and self.world > 1:
@@ -147,22 +218,24 @@ class ShardedRecommender:
             sv[:, s_bytes:].view(torch.int32).copy_(pos.reshape(self.world, nq * k))    # int64 -> int32 on the wire
             recv = torch.empty_like(send)
             all_to_all_bytes(recv, send, self.group)                          # ONE collective per step
-            cand_scores, cand_pos = self.engine.merge(recv, self.world, nq, k, 0, nq)
-            out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
-            out["candidate_scores"] = cand_scores
-            out["user_offset"] = q0
-            return out
-        s_bytes, chunk = packed_layout(B, k)
-        buf = torch.empty(chunk, dtype=torch.uint8, device=scores.device)
-        buf[:B * k * 4].view(torch.float32).copy_(scores.reshape(-1))
-        buf[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))        # int64 -> int32 on the wire
-        gathered = torch.empty(chunk * self.world, dtype=torch.uint8, device=scores.device)
-        all_gather_bytes(gathered, buf, self.group)                           # ONE collective per step
-        cand_scores, cand_pos = self.engine.merge(gathered, self.world, B, k, q0, nq)
+            cand_scores, cand_pos = self._merge(recv, nq, k, 0, nq, k_out, inexact)
+        else:
+            s_bytes, chunk = packed_layout(B, k)
+            buf = torch.empty(chunk, dtype=torch.uint8, device=scores.device)
+            buf[:B * k * 4].view(torch.float32).copy_(scores.reshape(-1))
+            buf[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))        # int64 -> int32 on the wire
+            gathered = torch.empty(chunk * self.world, dtype=torch.uint8, device=scores.device)
+            all_gather_bytes(gathered, buf, self.group)                       # ONE collective per step
+            cand_scores, cand_pos = self._merge(gathered, B, k, q0, nq, k_out, inexact)
         out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
         out["candidate_scores"] = cand_scores
         out["user_offset"] = q0
         return out
+
+    def _merge(self, buf, n_users, k, q0, nq, k_out, inexact):
+        if k == k_out:
+            return self.engine.merge(buf, self.world, n_users, k, q0, nq)
+        return self.engine.merge(buf, self.world, n_users, k, q0, nq, k_out, inexact)
 
     @torch.no_grad()
     def recommend_all(self, user_categorical, user_numerical, top_k: int = 10, stage1_k: int = 500):

@@ -39,6 +39,7 @@ constexpr int CAND_CAP = 8192;     // candidate keys per query (64 KB LDS sort)
 constexpr int SAMPLE_RANK = 64;    // r
 constexpr int KMAX = 2048;
 constexpr int FIX_BUF = 4096;      // fix-up scan buffer (keys)
+constexpr int FIX_GRID_Q = 256;    // queries worked on at a time by the fix-up kernels
 constexpr int SAMPLE_G = 256;      // rows per sample block (== BP of every search shape / divides it)
 
 // ---- epilogues (lane <-> query, registers <-> corpus rows) ---------------------------
@@ -189,17 +190,20 @@ __global__ __launch_bounds__(512) void finalize_kernel(const unsigned long long*
 
 // step 5a: exact streaming scan of one corpus slice for a failed query
 __global__ __launch_bounds__(512) void fixup_scan_kernel(const float* X, long long ldx, long long nrows, int d,
-                                                         const float* Q, long long ldq, const int* fail,
+                                                         const float* Q, long long ldq, const int* fail, int nq,
                                                          int k, int nslices, unsigned long long* scratch) {
     __shared__ __attribute__((aligned(16))) unsigned long long buf[FIX_BUF];
     __shared__ __attribute__((aligned(16))) float qv[2048];
     __shared__ unsigned long long thr;
     __shared__ int count;
-    // 1-D grid (query-major): gridDim.y is limited to 65535 but nq may reach 2^24
-    const int q = blockIdx.x / nslices, s = blockIdx.x - q * nslices;
-    if (!fail[q]) return;
+    // 1-D grid (query-major) of nslices x min(nq, FIX_GRID_Q) blocks, each looping over its queries: failures are
+    // rare, and one block per (query, slice) cost 0.07 ms of empty blocks at 4096 queries
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int NW = 8, U = 8;
+    const int s = blockIdx.x % nslices;
+    if (fail[nq] == 0) return;                                 // fail[nq] = number of failed queries
+    for (int q = blockIdx.x / nslices; q < nq; q += gridDim.x / nslices) {
+    if (!fail[q]) continue;                                    // block-uniform
     for (int i = tid; i < d; i += 512) qv[i] = Q[(long long)q * ldq + i];
     if (tid == 0) { thr = 0ull; count = 0; }
     __syncthreads();
@@ -261,49 +265,71 @@ __global__ __launch_bounds__(512) void fixup_scan_kernel(const float* X, long lo
     const int c = count;
     unsigned long long* dst = scratch + ((long long)q * nslices + s) * k;
     for (int i = tid; i < k; i += 512) dst[i] = (i < c) ? buf[i] : 0ull;
+    __syncthreads();                                           // before the next query resets count / thr / buf
+    }
 }
 
 // step 5b: merge the slices of a failed query
-__global__ __launch_bounds__(512) void fixup_merge_kernel(const unsigned long long* scratch, const int* fail,
+__global__ __launch_bounds__(512) void fixup_merge_kernel(const unsigned long long* scratch, const int* fail, int nq,
                                                           int k, int nslices, float* outD, long long* outI,
                                                           long long pos_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-    const int q = blockIdx.x;
-    if (!fail[q]) return;
+    if (fail[nq] == 0) return;
     const int total = k * nslices;
     int P = 2;
     while (P < total) P <<= 1;
-    for (int i = threadIdx.x; i < P; i += blockDim.x)
-        keys[i] = (i < total) ? scratch[(long long)q * total + i] : 0ull;
-    __syncthreads();
-    bitonic_desc(keys, P);
-    write_result(keys, total < k ? total : k, k, q, outD, outI, pos_offset);
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+        if (!fail[q]) continue;
+        for (int i = threadIdx.x; i < P; i += blockDim.x)
+            keys[i] = (i < total) ? scratch[(long long)q * total + i] : 0ull;
+        __syncthreads();
+        bitonic_desc(keys, P);
+        write_result(keys, total < k ? total : k, k, q, outD, outI, pos_offset);
+        __syncthreads();
+    }
 }
 
-// Cross-shard merge: n_lists sorted top-k lists per query (one per corpus shard,
-// positions already global) -> the global top-k.  One block per query, bitonic sort in LDS.
-__global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, const char* pos, int n_lists,
+// Cross-shard merge: n_lists sorted lists of list_k entries per query (one per corpus shard, positions
+// already global) -> the global top-k.  One block per query, bitonic sort in LDS.
+// Short lists (list_k < k, amdrec_topk_merge_partial): a shard sends only its best list_k rows; the merged top-k is the
+// exact global top-k iff no shard was cut off above the merged k-th score, i.e. every FULL list's last score is below
+// it (rows the shard did not send score no more than its last entry).  A query for which that cannot be shown - a full
+// list whose last score reaches the merged k-th, ties included, or fewer than k merged entries - is counted in *inexact.
+__global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, const char* pos, int n_lists, int list_k,
                                                          long long list_stride_bytes, long long q0, int k,
-                                                         float* outD, long long* outI) {
+                                                         float* outD, long long* outI, int* inexact) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     const long long q = blockIdx.x;
-    const int total = n_lists * k;
+    const int total = n_lists * list_k;
     int P = 2;
     while (P < total) P <<= 1;
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         unsigned long long key = 0ull;
         if (i < total) {
-            const int g = i / k, j = i - g * k;
+            const int g = i / list_k, j = i - g * list_k;
             const float* sg = reinterpret_cast<const float*>(scores + (long long)g * list_stride_bytes);
             const int* pg = reinterpret_cast<const int*>(pos + (long long)g * list_stride_bytes);
-            const long long p = pg[(q0 + q) * k + j];
-            const float sc = sg[(q0 + q) * k + j];
+            const long long p = pg[(q0 + q) * list_k + j];
+            const float sc = sg[(q0 + q) * list_k + j];
             if (p >= 0 && sc == sc) key = make_key(sc, (uint32_t)p);
         }
         keys[i] = key;
     }
     __syncthreads();
     bitonic_desc(keys, P);
+    if (inexact != nullptr) {
+        const unsigned long long kth = k <= P ? keys[k - 1] : 0ull;
+        bool cut = false;
+        for (int g = threadIdx.x; g < n_lists; g += blockDim.x) {
+            const float* sg = reinterpret_cast<const float*>(scores + (long long)g * list_stride_bytes);
+            const int* pg = reinterpret_cast<const int*>(pos + (long long)g * list_stride_bytes);
+            const long long p = pg[(q0 + q) * list_k + list_k - 1];
+            const float sc = sg[(q0 + q) * list_k + list_k - 1];
+            const bool full = p >= 0 && sc == sc;
+            cut |= full && (kth == 0ull || sc >= key_score(kth));
+        }
+        if (__syncthreads_or(cut) && threadIdx.x == 0) atomicAdd(inexact, 1);
+    }
     write_result(keys, total < k ? total : k, k, q, outD, outI, 0);
 }
 
@@ -640,7 +666,7 @@ constexpr int SPLIT_MAX_NQ = 128;
 // saw (may exceed seg_cap: the excess went to the overflow block, ocnt[q] entries).  The generic GEMM pass writes one
 // segment (nseg = 1, seg_cap = CAND_CAP, no overflow).
 template <bool SPLIT>
-__global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long* cand, long long cstride, const int* segcnt,
+__global__ __launch_bounds__(512, 2) void finalize_mixed_kernel(unsigned long long* cand, long long cstride, const int* segcnt,
                                                              int nseg, int seg_cap, const int* ocnt, int cap,
                                                              int k, long long nrows, const float* tau,
                                                              const float* max_norm, const float* X, long long ldx,
@@ -770,9 +796,11 @@ __global__ __launch_bounds__(512) void finalize_mixed_kernel(unsigned long long*
         if (tid == 0) { m_out[q] = m; eps_out[q] = eps; }
         return;
     }
-    // fp32 re-score, one wave per candidate, 16 candidates (random 1 KB rows: latency-bound) in flight per wave
+    // fp32 re-score, one wave per candidate, 8 candidates (random 1 KB rows: latency-bound) in flight per wave; two
+    // workgroups per CU (<= 128 VGPRs): with 16 in flight the kernel needed 169 and ran one workgroup per CU, its select
+    // and sort phases - barriers and LDS latency - covered by nothing
     const int d4 = d >> 2;
-    constexpr int RU = 16;
+    constexpr int RU = 8;
     for (int i0 = w; i0 < m; i0 += 8 * RU) {
         float a[RU];
         uint32_t pos[RU];
@@ -978,15 +1006,16 @@ static hipError_t run_passes(const float* X, long long ldx, long long nrows, int
 
 using namespace amdrec;
 
-extern "C" int amdrec_topk_merge(const float* scores, const int32_t* pos, int n_lists, int64_t list_stride_bytes,
-                                 int64_t q0, int64_t nq, int k, float* out_scores, int64_t* out_pos,
-                                 void* stream) {
-    REQUIRE(n_lists >= 1 && k >= 1 && (long long)n_lists * k <= 16384, "n_lists*k must be in [1,16384]");
+static int topk_merge_impl(const float* scores, const int32_t* pos, int n_lists, int list_k, int64_t list_stride_bytes,
+                           int64_t q0, int64_t nq, int k, float* out_scores, int64_t* out_pos, int32_t* n_inexact,
+                           void* stream) {
+    REQUIRE(n_lists >= 1 && list_k >= 1 && k >= 1 && (long long)n_lists * list_k <= 16384 && k <= 16384,
+            "n_lists*list_k and k must be in [1,16384]");
     REQUIRE(list_stride_bytes % 4 == 0 && q0 >= 0, "bad stride/offset");
     if (nq <= 0) return AMDREC_OK;
     REQUIRE(scores && pos && out_scores && out_pos, "null pointer");
     int P = 2;
-    while (P < n_lists * k) P <<= 1;
+    while (P < n_lists * list_k) P <<= 1;
     static PerDeviceOnce attr_done;
     if (attr_done.pending()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel),
@@ -994,10 +1023,24 @@ extern "C" int amdrec_topk_merge(const float* scores, const int32_t* pos, int n_
         attr_done.mark();
     }
     hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(512), (size_t)P * 8,
-                       reinterpret_cast<hipStream_t>(stream), (const char*)scores, (const char*)pos, n_lists,
-                       (long long)list_stride_bytes, (long long)q0, k, out_scores, (long long*)out_pos);
+                       reinterpret_cast<hipStream_t>(stream), (const char*)scores, (const char*)pos, n_lists, list_k,
+                       (long long)list_stride_bytes, (long long)q0, k, out_scores, (long long*)out_pos, (int*)n_inexact);
     HIP_TRY(hipGetLastError());
     return AMDREC_OK;
+}
+
+extern "C" int amdrec_topk_merge(const float* scores, const int32_t* pos, int n_lists, int64_t list_stride_bytes,
+                                 int64_t q0, int64_t nq, int k, float* out_scores, int64_t* out_pos,
+                                 void* stream) {
+    return topk_merge_impl(scores, pos, n_lists, k, list_stride_bytes, q0, nq, k, out_scores, out_pos, nullptr, stream);
+}
+
+extern "C" int amdrec_topk_merge_partial(const float* scores, const int32_t* pos, int n_lists, int list_k,
+                                         int64_t list_stride_bytes, int64_t q0, int64_t nq, int k, float* out_scores,
+                                         int64_t* out_pos, int32_t* n_inexact, void* stream) {
+    REQUIRE(n_inexact != nullptr, "n_inexact is null");
+    return topk_merge_impl(scores, pos, n_lists, list_k, list_stride_bytes, q0, nq, k, out_scores, out_pos, n_inexact,
+                           stream);
 }
 
 extern "C" int amdrec_flat_search_workspace(int64_t nq, int64_t nrows, int k, size_t* bytes) {
@@ -1056,10 +1099,10 @@ extern "C" int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld
     unsigned long long* fix = reinterpret_cast<unsigned long long*>(ws + pl.off_fix);
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, cand, cnt, CAND_CAP, k,
                        (long long)nrows, fail, out_scores, (long long*)out_pos, (long long)pos_offset);
-    hipLaunchKernelGGL(fixup_scan_kernel, dim3((unsigned)(pl.nslices * nq)), dim3(512), 0, st, corpus,
-                       (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, k,
+    hipLaunchKernelGGL(fixup_scan_kernel, dim3((unsigned)(pl.nslices * (nq < FIX_GRID_Q ? nq : FIX_GRID_Q))), dim3(512), 0, st, corpus,
+                       (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, (int)nq, k,
                        pl.nslices, fix);
-    hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, fix, fail, k,
+    hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)(nq < FIX_GRID_Q ? nq : FIX_GRID_Q)), dim3(512), CAND_CAP * 8, st, fix, fail, (int)nq, k,
                        pl.nslices, out_scores, (long long*)out_pos, (long long)pos_offset);
     HIP_TRY(hipGetLastError());
     if (n_fixup) HIP_TRY(hipMemcpyAsync(n_fixup, fail + nq, sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -1195,10 +1238,10 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
         }
     }
     ProfScope prof_fix("search_fixup", 0.0, 0.0, st);
-    hipLaunchKernelGGL(fixup_scan_kernel, dim3((unsigned)(pl.nslices * nq)), dim3(512), 0, st, corpus,
-                       (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, k,
+    hipLaunchKernelGGL(fixup_scan_kernel, dim3((unsigned)(pl.nslices * (nq < FIX_GRID_Q ? nq : FIX_GRID_Q))), dim3(512), 0, st, corpus,
+                       (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, (int)nq, k,
                        pl.nslices, fix);
-    hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, fix, fail, k,
+    hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)(nq < FIX_GRID_Q ? nq : FIX_GRID_Q)), dim3(512), CAND_CAP * 8, st, fix, fail, (int)nq, k,
                        pl.nslices, out_scores, (long long*)out_pos, (long long)pos_offset);
     HIP_TRY(hipGetLastError());
     if (n_fixup) HIP_TRY(hipMemcpyAsync(n_fixup, fail + nq, sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -92,6 +92,22 @@ def merge_shards(Ds, Is, offsets, k):
     return _merge(D, I, k)
 
 
+def merge_partial(Ds, Is, offsets, k):
+    """Merge of SHORT per-shard lists (each [nq, list_k], list_k <= k): -> (D, I, inexact[nq] bool).  The merged top-k
+    is proven exact when every FULL list's last score is strictly below the merged k-th score (rows a shard did not
+    send score at most its last entry); ties and a merged list shorter than k count as not proven."""
+    D, I = merge_shards(Ds, Is, offsets, k)
+    nq = D.shape[0]
+    inexact = np.zeros(nq, dtype=bool)
+    for q in range(nq):
+        have_k = I.shape[1] >= k and I[q, k - 1] >= 0
+        for d, i in zip(Ds, Is):
+            full = i[q, -1] >= 0 and not np.isnan(d[q, -1])
+            if full and (not have_k or d[q, -1] >= D[q, k - 1]):
+                inexact[q] = True
+    return D, I, inexact
+
+
 class FlatIndex:
     """FAISSIndex(index_type='Flat') restated: add / search with the wrapper's steps."""
 

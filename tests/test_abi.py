@@ -100,6 +100,8 @@ def test_host_only_entry_points_validate_arguments_without_a_gpu():
     assert lib.amdrec_select_topk(None, 0, 3, 5, None, 1, 500, 10, None, None, None, None) == -1   # bad task index
     assert lib.amdrec_topk_merge(None, None, 40, 96, 0, 1, 500, None, None, None) == -1            # 40*500 > 16384
     assert lib.amdrec_ivf_select(None, 0, None, 0, 10, None, None, None) == 0                      # nq = 0
+    assert lib.amdrec_topk_merge_partial(None, None, 8, 128, 96, 0, 1, 500, None, None, None, None) == -1   # no counter
+    assert b"n_inexact" in lib.amdrec_last_error()
 
 
 def test_model_workspace_queries_follow_the_architecture():

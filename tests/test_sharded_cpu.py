@@ -33,7 +33,7 @@ class OracleEngine:
         I = np.where(I >= 0, I + self.offset, -1)
         return torch.from_numpy(D), torch.from_numpy(I)
 
-    def merge(self, gathered, world, n_users, k, q0, nq):
+    def merge(self, gathered, world, n_users, k, q0, nq, k_out=None, inexact=None):
         s_bytes, chunk = packed_layout(n_users, k)
         raw = gathered.numpy()
         Ds, Is = [], []
@@ -41,7 +41,11 @@ class OracleEngine:
             c = raw[g * chunk:(g + 1) * chunk]
             Ds.append(c[:n_users * k * 4].view(np.float32).reshape(n_users, k)[q0:q0 + nq])
             Is.append(c[s_bytes:].view(np.int32).reshape(n_users, k)[q0:q0 + nq].astype(np.int64))
-        D, I = oracle.search.merge_shards(Ds, Is, [0] * world, k)
+        if k_out is None or k_out == k:
+            D, I = oracle.search.merge_shards(Ds, Is, [0] * world, k)
+        else:                                                   # short lists: the CPU statement of amdrec_topk_merge_partial
+            D, I, bad = oracle.search.merge_partial(Ds, Is, [0] * world, k_out)
+            inexact += int(bad.sum())
         return torch.from_numpy(D), torch.from_numpy(I)
 
     def rank(self, uc, un, cand_pos, top_k):
@@ -68,7 +72,7 @@ def _inputs(B=B):
     return tt_sd, rk_sd, ad_table, corpus, uc, un
 
 
-def _worker(rank, world, port, q, B=B, exchange="auto"):
+def _worker(rank, world, port, q, B=B, exchange="auto", shard_k=None, sort_corpus=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -77,11 +81,16 @@ def _worker(rank, world, port, q, B=B, exchange="auto"):
         tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(B)
         per = (N_ADS + world - 1) // world
         lo, hi = rank * per, min(N_ADS, (rank + 1) * per)
+        if sort_corpus:          # shard 0 holds user 0's best rows: the premise of short lists (random sharding) is false
+            emb = oracle.search.normalize_l2(oracle.towers.user_tower(tt_sd, uc, un))
+            order = np.argsort(-(oracle.search.normalize_l2(corpus) @ emb[0]), kind="stable")
+            corpus, ad_table = corpus[order], ad_table[order]
         eng = OracleEngine(tt_sd, rk_sd, corpus[lo:hi], lo, ad_table)
-        sr = ShardedRecommender(None, rank, world, lo, engine=eng, exchange=exchange)
+        sr = ShardedRecommender(None, rank, world, lo, engine=eng, exchange=exchange, shard_k=shard_k)
+        used_k = sr.list_k(K1)
         out = sr.recommend_device(torch.from_numpy(uc), torch.from_numpy(un), TOPK, K1)
         q.put((rank, out["user_offset"], out["ad_ids"].numpy(), out["scores"].numpy(),
-               out["candidate_ids"].numpy(), out["candidate_scores"].numpy()))
+               out["candidate_ids"].numpy(), out["candidate_scores"].numpy(), used_k, sr.shard_k))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -116,7 +125,7 @@ def test_two_rank_sharded_pipeline_equals_unsharded_oracle(B, exchange):
     oidx.add(corpus)
     ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
     covered = []
-    for rank, q0, ids, sc, cand, cs in res:
+    for rank, q0, ids, sc, cand, cs, _, _ in res:
         assert (q0, len(ids)) == user_slice(B, rank, world)
         for j in range(len(ids)):
             r = ref[q0 + j]
@@ -128,6 +137,61 @@ def test_two_rank_sharded_pipeline_equals_unsharded_oracle(B, exchange):
                 assert np.allclose(sc[ti, j], r["scores"][t], atol=1e-6)
             covered.append(q0 + j)
     assert covered == list(range(B))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("shard_k,sort_corpus,exchange", [(40, False, "auto"), (40, False, "all_gather"), (26, True, "auto")])
+def test_short_shard_lists_are_proven_exact_or_repeated(shard_k, sort_corpus, exchange):
+    """Short lists (amdrec.sharded, amdrec_topk_merge_partial): 40 of 50 entries per shard on a randomly ordered corpus
+    -> proven exact, no repeat; 26 entries on a corpus sorted by user 0's score (all of user 0's best rows on shard 0)
+    -> the proof fails, the step is repeated with full lists and short lists are switched off.  Either way the result
+    is the unsharded oracle's, bit for bit."""
+    world, Bn = 2, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, Bn, exchange, shard_k, sort_corpus)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(Bn)
+    if sort_corpus:
+        emb = oracle.search.normalize_l2(oracle.towers.user_tower(tt_sd, uc, un))
+        order = np.argsort(-(oracle.search.normalize_l2(corpus) @ emb[0]), kind="stable")
+        corpus, ad_table = corpus[order], ad_table[order]
+    oidx = oracle.search.FlatIndex(256)
+    oidx.add(corpus)
+    ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
+    for rank, q0, ids, sc, cand, cs, used_k, shard_k_after in res:
+        assert used_k == shard_k
+        assert shard_k_after == (None if sort_corpus else shard_k)
+        for j in range(len(ids)):
+            r = ref[q0 + j]
+            assert np.array_equal(cand[j], r["candidate_ids"])
+            assert np.array_equal(cs[j], r["candidate_scores"])
+            assert ids[j].tolist() == r["ad_ids"]
+
+
+def test_short_list_length_and_merge_rule():
+    from amdrec.sharded import short_list_k
+    assert [short_list_k(500, w) for w in (1, 2, 4, 8)] == [500, 352, 192, 128]
+    assert short_list_k(50, 2) == 50                                   # saves less than a fifth: full lists
+    # the merge rule on hand-made lists: shard 0 sends (9, 8), shard 1 sends (7, 1) for k = 3
+    D0, I0 = np.array([[9., 8.]], dtype=np.float32), np.array([[0, 1]])
+    D1, I1 = np.array([[7., 1.]], dtype=np.float32), np.array([[5, 6]])
+    D, I, bad = oracle.search.merge_partial([D0, D1], [I0, I1], [0, 0], 3)
+    assert I.tolist() == [[0, 1, 5]] and bad.tolist() == [True]        # shard 0's last (8) >= merged 3rd (7): not proven
+    D, I, bad = oracle.search.merge_partial([D0, D1], [I0, I1], [0, 0], 2)
+    assert I.tolist() == [[0, 1]] and bad.tolist() == [True]           # tie with the cut-off entry counts as not proven
+    D0b = np.array([[9., 6.]], dtype=np.float32)
+    D, I, bad = oracle.search.merge_partial([D0b, D1], [I0, I1], [0, 0], 2)
+    assert I.tolist() == [[0, 5]] and bad.tolist() == [False]          # both lasts (6, 1) below the merged 2nd (7)
+    D1s, I1s = np.array([[7., -np.inf]], dtype=np.float32), np.array([[5, -1]])   # a shard with one row: not full
+    D, I, bad = oracle.search.merge_partial([D0b, D1s], [I0, I1s], [0, 0], 3)
+    assert I.tolist() == [[0, 5, 1]] and bad.tolist() == [True]        # shard 0 full and its last (6) IS the merged 3rd
 
 
 def test_user_slice_and_layout():

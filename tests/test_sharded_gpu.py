@@ -53,6 +53,59 @@ def test_merge_of_shard_topk_is_bit_identical_to_unsharded_search():
     assert torch.equal(pos, rp) and torch.equal(sc, rs)
 
 
+@pytest.mark.parametrize("list_k,clustered", [(128, False), (96, False), (128, True)])
+def test_short_list_merge_is_proven_exact_or_flagged(list_k, clustered):
+    """amdrec_topk_merge_partial over 8 emulated shards of a 200k-row corpus, top-500: every shard sends its best
+    list_k rows.  Random sharding: the merge equals the unsharded HIP search bit for bit, equals the oracle's merge rule
+    (oracle.search.merge_partial) and counts nothing inexact.  Clustered: the rows nearest to queries 0..3 all sit on
+    shard 2, whose list is cut off above the merged 500th score -> exactly those queries are counted."""
+    from amdrec.index import FAISSIndex
+    from amdrec.sharded import HipEngine, packed_layout
+    n, nq, k, G = 200_000, 24, 500, 8
+    xb, xq = synth.unit_corpus(n, 256, seed=11), synth.unit_corpus(nq, 256, seed=12)
+    per = n // G
+    if clustered:
+        rng = np.random.default_rng(5)
+        for qi in range(4):                                   # 400 near-copies of each of the first four queries on shard 2
+            rows = xq[qi][None, :] + 0.05 * rng.standard_normal((400, 256)).astype(np.float32)
+            xb[2 * per + 400 * qi:2 * per + 400 * (qi + 1)] = rows / np.linalg.norm(rows, axis=1, keepdims=True)
+    full = FAISSIndex(256, index_type="Flat")
+    full.add(xb)
+    q = torch.from_numpy(xq).cuda()
+    ref_pos, ref_sc = full.search_device(q, k, return_positions=True)
+    s_bytes, chunk = packed_layout(nq, list_k)
+    gathered = torch.empty(chunk * G, dtype=torch.uint8, device="cuda")
+    Ds, Is = [], []
+    for g in range(G):
+        lo, hi = g * per, (g + 1) * per
+        sh = FAISSIndex(256, index_type="Flat")
+        sh.add(xb[lo:hi])
+        pos, sc = sh.search_device(q, list_k, return_positions=True, pos_offset=lo)
+        c = gathered[g * chunk:(g + 1) * chunk]
+        c[:nq * list_k * 4].view(torch.float32).copy_(sc.reshape(-1))
+        c[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))
+        Ds.append(sc.cpu().numpy())
+        Is.append(pos.cpu().numpy())
+    oD, oI, bad = oracle.search.merge_partial(Ds, Is, [0] * G, k)
+    inexact = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng = HipEngine(None, 0)
+    sc, pos = eng.merge(gathered, G, nq, list_k, 0, nq, k, inexact)
+    assert np.array_equal(pos.cpu().numpy(), oI) and np.array_equal(sc.cpu().numpy(), oD)
+    assert int(inexact.item()) == int(bad.sum())
+    if clustered:
+        assert bad[:4].all() and not bad[4:].any()
+        ok = slice(4, nq)
+    else:
+        # 8 shards x 96 leaves less slack (62.5 +- 7.4 per shard): whatever is not proven must at least be flagged
+        ok = ~bad
+        assert list_k == 96 or not bad.any()
+    ok = torch.from_numpy(np.arange(nq)[ok]).cuda()
+    assert torch.equal(pos[ok], ref_pos[ok]) and torch.equal(sc[ok], ref_sc[ok])
+    # a sub-range of the users, as a rank merging only its own slice does; the counter accumulates
+    sc2, pos2 = eng.merge(gathered, G, nq, list_k, 3, 9, k, inexact)
+    assert np.array_equal(pos2.cpu().numpy(), oI[3:12]) and int(inexact.item()) == int(bad.sum()) + int(bad[3:12].sum())
+
+
 def test_sharded_recommender_single_rank_rccl_matches_pipeline():
     import torch.distributed as dist
     from amdrec.sharded import ShardedRecommender
