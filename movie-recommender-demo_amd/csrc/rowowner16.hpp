@@ -48,8 +48,9 @@ struct Ring {
     lds_byte* lds_dma;
     lds_byte* lds_rd;
     int issued, total;
-    uint32_t rpos;
-    int rfrags;
+    int slot;                    // ring slot of the chunk being read
+    const lds_byte* cbase;       // its address for this lane (lds_rd + slot * CHUNK_BYTES)
+    int gdyn;                    // group within the chunk, for read4_dyn only
 
     __device__ __forceinline__ void issue() {
         if (DBG & 1) { ++issued; return; }
@@ -73,17 +74,43 @@ struct Ring {
         lds_rd = lds + lane * 16;
         issued = 0;
         total = total_chunks;
-        rpos = 0;
-        rfrags = 0;
+        slot = -1;
+        cbase = lds_rd;
+        gdyn = 0;
 #pragma unroll
         for (int c = 0; c < DEPTH + 1; ++c) issue();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * DEPTH) : "memory");
         __builtin_amdgcn_s_barrier();
     }
+    // first read of a chunk: certify the one after it, move to its slot
+    __device__ __forceinline__ void next_chunk() {
+        certify_next();
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+        cbase = lds_rd + (uint32_t)slot * CHUNK_BYTES;
+    }
+    // Fragment group G (0..3, a compile-time constant) of the current chunk: a chunk is 4 groups of 4 fragment sets, every
+    // GEMM / FFN step starts on a chunk boundary and its loops are unrolled, so the position inside the chunk is known
+    // at compile time: the four reads are one base register + immediate offsets, and the ring bookkeeping (slot
+    // wrap-around, barrier, DMA) runs once per chunk instead of the per-group address arithmetic and boundary test.
+    template <int G>
     __device__ __forceinline__ void read4(f16x8 (&f)[4]) {
-        if ((rfrags & (CHUNK_FRAGS - 1)) == 0) certify_next();
-        const lds_byte* a = lds_rd + rpos;
-        if ((DBG & 4) && rfrags != 0) {
+        static_assert(G >= 0 && G < 4 && CHUNK_FRAGS == 16, "four groups of four fragment sets per chunk");
+        if (G == 0) next_chunk();
+        if (DBG & 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(f[u]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                f[u] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(cbase + (4 * G + u) * FRAG_BYTES);
+        }
+    }
+    // the same with the group index at run time (heads: 10 groups per hidden tile); align() before the first use
+    __device__ __forceinline__ void align() { gdyn = 0; }
+    __device__ __forceinline__ void read4_dyn(f16x8 (&f)[4]) {
+        if (gdyn == 0) next_chunk();
+        const lds_byte* a = cbase + (uint32_t)gdyn * (4 * FRAG_BYTES);
+        if (DBG & 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(f[u]));
         } else {
@@ -91,9 +118,7 @@ struct Ring {
             for (int u = 0; u < 4; ++u)
                 f[u] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(a + u * FRAG_BYTES);
         }
-        rpos += 4 * FRAG_BYTES;
-        if (rpos >= RING_BYTES) rpos -= RING_BYTES;
-        rfrags += 4;
+        gdyn = (gdyn + 1) & 3;
     }
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
@@ -164,21 +189,25 @@ __device__ __forceinline__ void prepare(const f32x4 (&x)[16], float s, lds_cfloa
     }
 }
 
+// groups I .. 63 of one 256 x 256 GEMM (group I = k-step I / 8, tile pair I % 8); `cur` holds group I's fragments
+template <int I>
+__device__ __forceinline__ void gemm256_groups(Ring& ring, f16x8 (&cur)[4], const f16x8 (&xh)[8], const f16x8 (&xl)[8],
+                                               f32x4 (&acc)[16]) {
+    constexpr int ks = I >> 3, tp = I & 7;
+    f16x8 nxt[4];
+    if constexpr (I < 63) ring.template read4<(I + 1) & 3>(nxt);
+    group6(cur, xh[ks], xl[ks], acc[2 * tp], acc[2 * tp + 1]);
+    if constexpr (I < 63) gemm256_groups<I + 1>(ring, nxt, xh, xl, acc);
+}
+template <int I0>
+__device__ __forceinline__ void gemm256_from(Ring& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4 (&acc)[16]) {
+    f16x8 cur[4];
+    ring.template read4<0>(cur);
+    gemm256_groups<I0>(ring, cur, xh, xl, acc);
+}
+
 __device__ __forceinline__ void gemm256(Ring& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4 (&acc)[16]) {
-    f16x8 cur[4], nxt[4];
-    ring.read4(cur);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int tp = 0; tp < 8; ++tp) {
-            const bool last = ks == 7 && tp == 7;
-            if (!last) ring.read4(nxt);
-            group6(cur, xh[ks], xl[ks], acc[2 * tp], acc[2 * tp + 1]);
-            if (!last) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
-            }
-        }
+    gemm256_from<0>(ring, xh, xl, acc);
 }
 
 __device__ __forceinline__ void layer_norm(f32x4 (&y)[16], lds_cfloat* pb, int gamma, int beta, float eps) {
@@ -243,25 +272,26 @@ __device__ __forceinline__ void init_pair(f32x4& a0, f32x4& a1, lds_cfloat* pb, 
     }
 }
 
+template <bool S1, bool S2, int GI>
+__device__ __forceinline__ void ffn_groups(Ring& ring, f16x8 (&cur)[4], const f16x8 (&xh)[8], const f16x8 (&xl)[8],
+                                           f32x4& a10, f32x4& a11, f32x4 (&acc2)[16], const f16x8& hh, const f16x8& hl) {
+    constexpr int NG = (S1 ? 8 : 0) + (S2 ? 8 : 0);          // groups in this step (a multiple of 4: whole chunks)
+    constexpr bool is1 = S1 && (!S2 || (GI & 1) == 0);
+    constexpr int u = (S1 && S2) ? GI >> 1 : GI;
+    f16x8 nxt[4];
+    if constexpr (GI < NG - 1) ring.template read4<(GI + 1) & 3>(nxt);
+    if constexpr (is1) group6(cur, xh[u], xl[u], a10, a11);
+    else group6(cur, hh, hl, acc2[2 * u], acc2[2 * u + 1]);
+    if constexpr (GI < NG - 1) ffn_groups<S1, S2, GI + 1>(ring, nxt, xh, xl, a10, a11, acc2, hh, hl);
+}
+
 // One FFN step: 8 x { stage-1 group (W_1 tiles 2t, 2t+1 at ks = u), stage-2 group (W_2 tiles 2u, 2u+1 at k-step t-1) }
 template <bool S1, bool S2>
 __device__ __forceinline__ void ffn_step(Ring& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4& a10, f32x4& a11,
                                          f32x4 (&acc2)[16], const f16x8& hh, const f16x8& hl) {
-    constexpr int NG = (S1 ? 8 : 0) + (S2 ? 8 : 0);          // groups in this step
-    f16x8 cur[4], nxt[4];
-    ring.read4(cur);
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        if (gi < NG - 1) ring.read4(nxt);
-        const bool is1 = S1 && (!S2 || (gi & 1) == 0);
-        const int u = (S1 && S2) ? gi >> 1 : gi;
-        if (is1) group6(cur, xh[u], xl[u], a10, a11);
-        else group6(cur, hh, hl, acc2[2 * u], acc2[2 * u + 1]);
-        if (gi < NG - 1) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) cur[v] = nxt[v];
-        }
-    }
+    f16x8 cur[4];
+    ring.template read4<0>(cur);
+    ffn_groups<S1, S2, 0>(ring, cur, xh, xl, a10, a11, acc2, hh, hl);
 }
 
 __device__ __forceinline__ void phase_ffn_ln(Ring& ring, const Phase& P, f32x4 (&x)[16], lds_cfloat* pb) {
@@ -335,6 +365,7 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
     for (int ks = 0; ks < 8; ++ks) split8(x[2 * ks], x[2 * ks + 1], s, xh[ks], xl[ks]);
     const float sh = x3::hidden_scale(fmaf(P.hn * 8192.0f, inv, P.hb));
     const float b1s = s * P.sw1, c1 = sh * inv / P.sw1, un2 = 1.0f / (P.sw2 * sh);
+    ring.align();                                             // the phase starts on a chunk boundary
     for (int task = 0; task < P.n_tasks; ++task) {
         f32x4 acc2[4];
         init_pair(acc2[0], acc2[1], pb, G.hb2[task], 0, P.sw2 * sh);
@@ -343,10 +374,10 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
             f32x4 a10, a11;
             init_pair(a10, a11, pb, P.b1 + task * P.n_steps * 32, 2 * t, b1s);
             f16x8 cur[4], nxt[4];
-            ring.read4(cur);
+            ring.read4_dyn(cur);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (u < 7) ring.read4(nxt);
+                if (u < 7) ring.read4_dyn(nxt);
                 group6(cur, xh[u], xl[u], a10, a11);
                 if (u < 7) {
 #pragma unroll
@@ -357,7 +388,7 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
             hidden_planes(a10, a11, c1, hh, hl);
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                ring.read4(cur);
+                ring.read4_dyn(cur);
                 group6(cur, hh, hl, acc2[2 * pr], acc2[2 * pr + 1]);
             }
         }
