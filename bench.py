@@ -12,8 +12,9 @@ through the whole hot path with inputs resident in HBM:
     UserTower -> L2 renorm -> exact inner-product top-500 -> TransformerRanker on the 500
     candidates of every user -> top-10 by CTR logit (+ sigmoid of the 3 tasks).
 N > 1: the corpus is row-sharded over the ranks (1M/N rows each), every rank searches its shard
-for the global batch (512*N users), the per-shard top-500 lists are exchanged with one RCCL
-all-gather, each rank merges and ranks its own 512 users ("scaling": "weak").
+for the global batch (512*N users), the per-shard lists (short, proven exact by the merge:
+amdrec.sharded) are exchanged with one RCCL all-to-all, each rank merges and ranks its own 512
+users ("scaling": "weak").
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -253,7 +254,18 @@ def main():
             runner.shard_k = None
             step()
     barrier()
-    _lib.profile_enable(True)                # HIP events around every GEMM launch, on the launch stream
+    # Per-kernel table: HIP events around EVERY tagged launch, in a pre-pass outside the timed region.  An event pair
+    # costs the stream ~10 us of idle GPU per launch (kernel trace: 0.2 us between untimed kernels, 5-10 us around timed
+    # ones), ~0.1 ms over the ~10 tagged launches of a step, so the timed region times only the dominant kernel.
+    n_pre = max(1, min(5, args.steps))
+    _lib.profile_enable(True)
+    for _ in range(n_pre):
+        step()
+    torch.cuda.synchronize(device)
+    prof_all = _lib.profile_report()
+    dom_tag = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else ""
+    barrier()
+    _lib.profile_enable(True, only=dom_tag)  # HIP events around the dominant kernel's launches, on the launch stream
     # per-step HIP events on the launch stream (torch's current stream IS the stream every kernel is enqueued on,
     # _lib.stream_ptr): median / p95 of the step time
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -287,7 +299,7 @@ def main():
             name, p = dom
             avg_ms = p["total_ms"] / p["launches"]
             achieved = p["flops"] / p["launches"] / (avg_ms * 1e-3) / 1e12
-            tr = pmc_traffic(name, list(prof))
+            tr = pmc_traffic(name, list(prof_all))
             x6 = name.endswith("_x6")       # fp32 GEMM computed as 6 bf16-MFMA products per MAC (exact 3-way split)
             x3 = name.endswith("_x3")       # fp32 chain computed as 3 fp16-MFMA products per MAC (two-plane split)
             peak = X3_PEAK_TFLOPS if x3 else (X6_PEAK_TFLOPS if x6 else FP32_PEAK_TFLOPS)
@@ -303,13 +315,14 @@ def main():
                         "kernel": name, "launches_per_step": p["launches"] / args.steps,
                         "avg_launch_ms": round(avg_ms, 4),
                         "alg_gflop_per_launch": round(p["flops"] / p["launches"] / 1e9, 3)}
-        kernels = {k: {"ms_per_step": round(v["total_ms"] / args.steps, 3),
+        # the other kernels: from the n_pre fully timed steps that ran before the timed region
+        kernels = {k: {"ms_per_step": round(v["total_ms"] / n_pre, 3),
                        "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None,
-                       "launches_per_step": v["launches"] / args.steps} for k, v in sorted(prof.items())}
-        sf = next((v for k, v in prof.items() if k.startswith("search_filter")), None)
+                       "launches_per_step": v["launches"] / n_pre} for k, v in sorted(prof_all.items())}
+        sf = next((v for k, v in prof_all.items() if k.startswith("search_filter")), None)
         search = None
         if args.index == "ivf":
-            search = ivf_search_stats(index, flat_ref, tt, uc, un, prof, args.steps)
+            search = ivf_search_stats(index, flat_ref, tt, uc, un, prof_all, n_pre)
         elif sf:
             ms = sf["total_ms"] / sf["launches"]
             mixed = getattr(index, "_mixed", False)      # bf16 shadow corpus read by the filter pass
@@ -352,7 +365,11 @@ def main():
                            "top_k": TOP_K, "corpus_rows_per_gpu": rows,
                            "parallelism": f"corpus row-sharded x{world}, ranker data-parallel over users",
                            "shard_lists": short_lists},
-                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "kernels": kernels, "search": search}
+                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "kernels": kernels,
+                "kernels_note": (f"per-kernel table from {n_pre} steps with HIP events around every tagged launch, run before "
+                                 "the timed region; the timed region records events around the dominant kernel only "
+                                 "(roofline.avg_launch_ms): an event pair costs the stream ~10 us of idle GPU per launch"),
+                "search": search}
         print(json.dumps(line), flush=True)
     if args.sweep and rank == 0 and world == 1:
         latency_sweep(rec, uc, un, device)

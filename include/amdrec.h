@@ -299,6 +299,9 @@ typedef struct {
     double total_ms, flops, bytes;
 } amdrec_profile_entry;
 int amdrec_profile_enable(int on);   /* also clears the counters */
+/* Time only the launches whose tag starts with tag_prefix (NULL or "" = all): an event pair costs the stream ~10 us of
+ * idle GPU per launch, so a benchmark times every kernel in a pre-pass and only its dominant one in the timed region. */
+int amdrec_profile_only(const char* tag_prefix);
 int amdrec_profile_report(amdrec_profile_entry* out /*host*/, int max_entries, int* n /*host*/);
 
 /* Request-side numerical prep (inference.py:186-195): out[r][c] = (log1p(|x[r][c]|) - mean[c]) / scale[c],

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "amdrec_l2_normalize": [_fp, _i64, _fp, _i64, _i64, _i32, _vp],
     "amdrec_remap_ids": [_vp, _vp, _i64, _vp, _i64, _vp],
     "amdrec_profile_enable": [_i32],
+    "amdrec_profile_only": [C.c_char_p],
     "amdrec_profile_report": [_vp, _i32, C.POINTER(_i32)],
     "amdrec_ranker_project_ads": [_vp, _vp, _i64, _fp, _i64, _vp, _sz, _vp],
     "amdrec_ranker_x3_prefix": [_vp, _fp, _i64, _i64, _i32, _fp, _i64, _fp, _i64, _vp, _sz, _vp],
@@ -122,7 +123,9 @@ class ProfileEntry(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-def profile_enable(on: bool):
+def profile_enable(on: bool, only: str = ""):
+    """Per-launch HIP-event timing on / off (clears the counters); ``only``: time just the tags with this prefix."""
+    check(load().amdrec_profile_only(only.encode() if only else None))
     check(load().amdrec_profile_enable(1 if on else 0))
 
 

@@ -1,5 +1,6 @@
 // libamdrec: error plumbing and version entry points.
 #include <stdarg.h>
+#include <string.h>
 
 #include "../../include/amdrec.h"
 #include "common.hpp"
@@ -28,6 +29,7 @@ struct Tag { std::string name; long long launches; double ms, flops, bytes; };
 std::vector<Rec> g_recs;
 std::vector<Tag> g_tags;
 std::vector<hipEvent_t> g_pool;
+std::string g_only;              // non-empty: only tags with this prefix are timed
 std::mutex g_mu;
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -39,6 +41,7 @@ hipEvent_t get_event() {
 ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : slot(-1), st(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_only.empty() && strncmp(tag, g_only.c_str(), g_only.size()) != 0) return;
     int t = -1;
     for (size_t i = 0; i < g_tags.size(); ++i) if (g_tags[i].name == tag) { t = (int)i; break; }
     if (t < 0) { g_tags.push_back(Tag{tag, 0, 0, 0, 0}); t = (int)g_tags.size() - 1; }
@@ -61,6 +64,12 @@ extern "C" int amdrec_profile_enable(int on) {
     amdrec::g_recs.clear();
     amdrec::g_tags.clear();
     amdrec::g_prof_on = on != 0;
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_profile_only(const char* tag_prefix) {
+    std::lock_guard<std::mutex> lk(amdrec::g_mu);
+    amdrec::g_only = tag_prefix ? tag_prefix : "";
     return AMDREC_OK;
 }
 
