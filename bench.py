@@ -460,16 +460,21 @@ def search_sweep(index, device, reps=20):
         for _ in range(3):
             index.search_device(qq, STAGE1_K, normalize=False)
         torch.cuda.synchronize(device)
-        _lib.profile_enable(True)
+        # whole call: no per-launch events inside (an event pair idles the stream ~10 us: five tags would add a quarter
+        # to a 0.16 ms call); the per-kernel breakdown comes from a second, event-instrumented loop
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
             index.search_device(qq, STAGE1_K, normalize=False)
         e1.record()
         torch.cuda.synchronize(device)
+        ms = e0.elapsed_time(e1) / reps
+        _lib.profile_enable(True)
+        for _ in range(reps):
+            index.search_device(qq, STAGE1_K, normalize=False)
+        torch.cuda.synchronize(device)
         prof = _lib.profile_report()
         _lib.profile_enable(False)
-        ms = e0.elapsed_time(e1) / reps
         # one corpus pass (bf16 shadow when the index runs the mixed search) + the fp32 rows of the k results
         alg_bytes = n * DIM * eb + B * DIM * 4 + B * STAGE1_K * 12 + (B * STAGE1_K * DIM * 4 if eb == 2 else 0)
         flops = 2.0 * B * n * DIM

@@ -145,10 +145,18 @@ __global__ __launch_bounds__(THR_NT) void sample_threshold_kernel(const float* S
     const int q = blockIdx.x, tid = threadIdx.x;
     const float* row = S + (long long)q * ld;
     float m = -INFINITY;
-    for (long long i = 4ll * tid; i < n; i += 4 * THR_NT) {      // n % 256 == 0, rows 16-byte aligned
-        const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+    // four independent 16-byte loads in flight per thread (one block per query: the pass is latency-bound)
+    for (long long i0 = 4ll * tid; i0 < n; i0 += 16 * THR_NT) {  // n % 256 == 0, rows 16-byte aligned
+        f32x4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m = (v[e] > m) ? v[e] : m;   // NaN compares false: ignored
+        for (int u = 0; u < 4; ++u) {
+            const long long i = i0 + 4ll * u * THR_NT;
+            v[u] = i < n ? *reinterpret_cast<const f32x4*>(row + i) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = (v[u][e] > m) ? v[u][e] : m;   // NaN compares false: ignored
     }
     mx[tid] = m;
     __syncthreads();
@@ -607,7 +615,10 @@ static hipError_t launch_scan(const uint16_t* X16, long long ld16, long long nro
 // error bound (atomic max over the float bits: norms are >= 0 so the unsigned order is the float order; NaN/inf propagate
 // and make every certificate fail -> exact fix-up path).
 __global__ __launch_bounds__(256) void bf16_rows_kernel(const float* x, long long rows, long long ld, int d,
-                                                        uint16_t* out, long long ld_out, float* max_norm) {
+                                                        uint16_t* out, long long ld_out, float* max_norm,
+                                                        int* zero = nullptr, long long n_zero = 0) {
+    // optional: clear n_zero ints (the search's counters, so that a search call needs no separate memset launch)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_zero; i += (long long)gridDim.x * 256) zero[i] = 0;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
@@ -1118,7 +1129,7 @@ extern "C" int amdrec_bf16_rows(const float* x, int64_t rows, int64_t ld, int di
     REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 8) == 0, "x must be 16-byte and out 8-byte aligned");
     hipLaunchKernelGGL(bf16_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), x, (long long)rows, (long long)ld, dim, out,
-                       (long long)ld_out, max_norm);
+                       (long long)ld_out, max_norm, (int*)nullptr, 0ll);
     HIP_TRY(hipGetLastError());
     return AMDREC_OK;
 }
@@ -1162,8 +1173,10 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     int* cnt = reinterpret_cast<int*>(ws + pl.off_cnt);
     int* ocnt = reinterpret_cast<int*>(ws + pl.off_ocnt);
     int* fail = reinterpret_cast<int*>(ws + pl.off_fail);
-    // cnt[nq], ocnt[nq] and fail[nq + 1] are adjacent in the plan: one fill
-    HIP_TRY(hipMemsetAsync(cnt, 0, (pl.off_fail - pl.off_cnt) + (size_t)(nq + 1) * 4, st));
+    // cnt[nq], ocnt[nq] and fail[nq + 1] are adjacent in the plan: cleared by the query-conversion kernel below (no
+    // separate fill launch: a launch costs ~5 us, a 32-query search 170)
+    const long long n_zero = (long long)((pl.off_fail - pl.off_cnt) / 4) + nq + 1;
+    if (nrows <= 0) HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)n_zero * 4, st));
     constexpr long long CSTRIDE = 2 * CAND_CAP;
     // corpus pass: the streaming kernel for the power-of-two dims it is instantiated for, else the generic tiles
     const bool streaming = nrows > 0 && (dim == 32 || dim == 64 || dim == 128 || dim == 256);
@@ -1174,7 +1187,7 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     if (nrows > 0) {
         uint16_t* q16 = reinterpret_cast<uint16_t*>(ws + pl.off_q16);
         hipLaunchKernelGGL(bf16_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, queries, (long long)nq,
-                           (long long)ld_queries, dim, q16, (long long)dim, (float*)nullptr);
+                           (long long)ld_queries, dim, q16, (long long)dim, (float*)nullptr, cnt, n_zero);
         // the bf16 matrices as float matrices of dim/2 columns (gemm_core.hpp, Shape::BF16)
         const float* X = reinterpret_cast<const float*>(corpus_bf16);
         const float* Q = reinterpret_cast<const float*>(q16);

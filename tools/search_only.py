@@ -21,12 +21,15 @@ for _ in range(3):
     idx.search_device(q, K, normalize=False)
 torch.cuda.synchronize()
 from amdrec import _lib
-_lib.profile_enable(True)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(reps):
+for _ in range(reps):                      # whole call, no per-launch events inside (they idle the stream ~10 us each)
     idx.search_device(q, K, normalize=False)
 e1.record(); torch.cuda.synchronize()
+_lib.profile_enable(True)
+for _ in range(reps):                      # per-kernel breakdown
+    idx.search_device(q, K, normalize=False)
+torch.cuda.synchronize()
 prof = _lib.profile_report()
 parts = " ".join(f"{k.replace('search_', '')}={v['total_ms'] / v['launches']:.4f}" for k, v in sorted(prof.items()) if v["launches"])
 print(f"B={B} k={K} prefilter={pref} lib={os.path.basename(_lib.LIB_PATH)} ms/search={e0.elapsed_time(e1) / reps:.4f}  {parts}")
