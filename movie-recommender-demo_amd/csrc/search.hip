@@ -36,6 +36,7 @@
 namespace amdrec {
 
 constexpr int CAND_CAP = 8192;     // candidate keys per query (64 KB LDS sort)
+constexpr long long CAND_STRIDE = 2 * CAND_CAP;   // mixed search: keys between the queries' blocks ([segments | overflow])
 constexpr int SAMPLE_RANK = 64;    // r
 constexpr int KMAX = 2048;
 constexpr int FIX_BUF = 4096;      // fix-up scan buffer (keys)
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     const int qbase = by * SCAN_QGROUP;
     auto append = [&](int q, unsigned long long key) {
         const int slot = atomicAdd(&lcnt[q - qbase], 1);
-        unsigned long long* blk = cand + (long long)q * (2 * CAND_CAP);
+        unsigned long long* blk = cand + (long long)q * CAND_STRIDE;
         if (slot < seg_cap) {
             blk[slot * nx + bx] = key;                     // slot-major: the used slots of all segments are the block's head
         } else {
@@ -1177,7 +1178,7 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     // separate fill launch: a launch costs ~5 us, a 32-query search 170)
     const long long n_zero = (long long)((pl.off_fail - pl.off_cnt) / 4) + nq + 1;
     if (nrows <= 0) HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)n_zero * 4, st));
-    constexpr long long CSTRIDE = 2 * CAND_CAP;
+    constexpr long long CSTRIDE = CAND_STRIDE;
     // corpus pass: the streaming kernel for the power-of-two dims it is instantiated for, else the generic tiles
     const bool streaming = nrows > 0 && (dim == 32 || dim == 64 || dim == 128 || dim == 256);
     const int nseg = streaming ? scan_segments(nrows, nq) : 1;

@@ -361,3 +361,31 @@ def test_hits_concentrated_in_one_workgroups_segment(hot_tiles, expect_fixup):
         hot |= set(range((5 + 256 * i) * 128, (5 + 256 * i + 1) * 128))
     assert len(set(I[0].cpu().tolist()) & hot) >= min(k, len(hot)) - 1      # query 0's top-k IS the hot rows
     assert (int(nfix.item()) >= 1) == expect_fixup
+
+
+def test_profile_hook_times_tagged_launches_and_honours_the_prefix_filter():
+    """amdrec_profile_enable / _only / _report (include/amdrec.h): every tagged launch is timed, or only the tags with
+    the given prefix (bench.py times every kernel in a pre-pass and only the dominant one in its timed region)."""
+    from amdrec import _lib
+    from amdrec.index import FAISSIndex
+    if _PREFILTER != "bf16":
+        pytest.skip("one engine is enough")
+    idx = FAISSIndex(256, index_type="Flat")
+    idx.add(_mk(20_000, 256, 1))
+    q = torch.from_numpy(_mk(4, 256, 2)).cuda()
+    idx.search_device(q, 10)
+    try:
+        _lib.profile_enable(True)
+        idx.search_device(q, 10)
+        idx.search_device(q, 10)
+        allp = _lib.profile_report()
+        assert {"search_threshold", "search_finalize_mixed", "search_fixup"} <= set(allp)
+        assert all(v["launches"] == 2 and v["total_ms"] > 0 for v in allp.values())
+        _lib.profile_enable(True, only="search_filter")
+        idx.search_device(q, 10)
+        only = _lib.profile_report()
+        assert list(only) == [t for t in allp if t.startswith("search_filter")] and len(only) == 1
+        assert next(iter(only.values()))["launches"] == 1
+    finally:
+        _lib.profile_enable(False)
+    assert _lib.profile_report() == {}
