@@ -40,7 +40,13 @@ using x3::RING_BYTES;
 using x3::TARGET_EXP;
 using x3::DEPTH;
 
-constexpr int WAVES = 8, ROWS_PER_WAVE = 16, ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
+#ifndef AMDREC_X3B_WAVES
+#define AMDREC_X3B_WAVES 8
+#endif
+#ifndef AMDREC_X3B_STAGGER
+#define AMDREC_X3B_STAGGER 1
+#endif
+constexpr int WAVES = AMDREC_X3B_WAVES, ROWS_PER_WAVE = 16, ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
 constexpr int DMA_PER_WAVE = CHUNK_FRAGS / WAVES;     // 2 fragment sets per wave and chunk
 
 struct Ring {
@@ -51,6 +57,16 @@ struct Ring {
     int slot;                    // ring slot of the chunk being read
     const lds_byte* cbase;       // its address for this lane (lds_rd + slot * CHUNK_BYTES)
     int gdyn;                    // group within the chunk, for read4_dyn only
+    unsigned long long t_wait, t_bar, t_dma;     // DBG & 16 (diagnostic build only): cycles in the DMA wait / barrier / DMA issue
+    unsigned long long t_lds, t_cal;             // DBG & 32: cycles waiting for a group's fragments; stamp-pair calibration
+    // DBG & 32: wait for the fragments of the group about to be multiplied, timed
+    __device__ __forceinline__ void timed_landed(f16x8 (&f)[4]) {
+        if (!(DBG & 32)) return;
+        const unsigned long long a = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+        const unsigned long long b = __builtin_amdgcn_s_memtime();
+        t_lds += b - a;
+    }
 
     __device__ __forceinline__ void issue() {
         if (DBG & 1) { ++issued; return; }
@@ -63,9 +79,36 @@ struct Ring {
                                              (__attribute__((address_space(3))) void*)(dst + u * FRAG_BYTES), 16, 0, 0);
         ++issued;
     }
+    // `late` waves (the second wave of each SIMD) issue their share of the next chunk's DMA two groups into the chunk
+    // instead of right behind the barrier: a DMA piece blocks its wave for ~100 cycles (in-kernel stamps: 13 % of a
+    // wave's time), and with both waves of a SIMD blocked at the same moment the matrix pipe idles; staggered, one
+    // multiplies while the other issues.  The counted vmcnt wait is unchanged: a wave still has issued exactly one more
+    // chunk by the time it certifies the next.
+    bool late;
     __device__ __forceinline__ void certify_next() {
+        if (DBG & 16) {
+            const unsigned long long a = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * (DEPTH - 1)) : "memory");
+            const unsigned long long b = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long c = __builtin_amdgcn_s_memtime();
+            if (!late) issue();
+            const unsigned long long d = __builtin_amdgcn_s_memtime();
+            t_wait += b - a; t_bar += c - b; t_dma += d - c;
+            return;
+        }
         if (!(DBG & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * (DEPTH - 1)) : "memory");
         if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+        if (!late) issue();
+    }
+    __device__ __forceinline__ void late_issue() {
+        if (!late) return;
+        if (DBG & 16) {
+            const unsigned long long c = __builtin_amdgcn_s_memtime();
+            issue();
+            t_dma += __builtin_amdgcn_s_memtime() - c;
+            return;
+        }
         issue();
     }
     __device__ __forceinline__ void start(const unsigned char* stream, int total_chunks, lds_byte* lds, int wave, int lane) {
@@ -77,6 +120,15 @@ struct Ring {
         slot = -1;
         cbase = lds_rd;
         gdyn = 0;
+        late = AMDREC_X3B_STAGGER && wave >= WAVES / 2;
+        t_wait = t_bar = t_dma = t_lds = 0;
+        t_cal = 0;
+        if (DBG & 32) {
+            const unsigned long long a = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long b = __builtin_amdgcn_s_memtime();
+            t_cal = b - a;
+        }
 #pragma unroll
         for (int c = 0; c < DEPTH + 1; ++c) issue();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * DEPTH) : "memory");
@@ -96,6 +148,7 @@ struct Ring {
     __device__ __forceinline__ void read4(f16x8 (&f)[4]) {
         static_assert(G >= 0 && G < 4 && CHUNK_FRAGS == 16, "four groups of four fragment sets per chunk");
         if (G == 0) next_chunk();
+        if (G == 2) late_issue();
         if (DBG & 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(f[u]));
@@ -109,6 +162,7 @@ struct Ring {
     __device__ __forceinline__ void align() { gdyn = 0; }
     __device__ __forceinline__ void read4_dyn(f16x8 (&f)[4]) {
         if (gdyn == 0) next_chunk();
+        if (gdyn == 2) late_issue();
         const lds_byte* a = cbase + (uint32_t)gdyn * (4 * FRAG_BYTES);
         if (DBG & 4) {
 #pragma unroll
@@ -196,6 +250,7 @@ __device__ __forceinline__ void gemm256_groups(Ring& ring, f16x8 (&cur)[4], cons
     constexpr int ks = I >> 3, tp = I & 7;
     f16x8 nxt[4];
     if constexpr (I < 63) ring.template read4<(I + 1) & 3>(nxt);
+    ring.timed_landed(cur);
     group6(cur, xh[ks], xl[ks], acc[2 * tp], acc[2 * tp + 1]);
     if constexpr (I < 63) gemm256_groups<I + 1>(ring, nxt, xh, xl, acc);
 }
@@ -280,6 +335,7 @@ __device__ __forceinline__ void ffn_groups(Ring& ring, f16x8 (&cur)[4], const f1
     constexpr int u = (S1 && S2) ? GI >> 1 : GI;
     f16x8 nxt[4];
     if constexpr (GI < NG - 1) ring.template read4<(GI + 1) & 3>(nxt);
+    ring.timed_landed(cur);
     if constexpr (is1) group6(cur, xh[u], xl[u], a10, a11);
     else group6(cur, hh, hl, acc2[2 * u], acc2[2 * u + 1]);
     if constexpr (GI < NG - 1) ffn_groups<S1, S2, GI + 1>(ring, nxt, xh, xl, a10, a11, acc2, hh, hl);
@@ -404,7 +460,7 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
     }
 }
 
-__global__ __launch_bounds__(512, 2) void ranker_x3b_kernel(Program G, Input in, long long rows, float* scratch,
+__global__ __launch_bounds__(64 * WAVES, 2) void ranker_x3b_kernel(Program G, Input in, long long rows, float* scratch,
                                                             float* x_out, long long ld_xout, float* logits,
                                                             long long ld_logits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -416,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void ranker_x3b_kernel(Program G, Input in,
     const long long rowc = row_ok ? row : rows - 1;
 
     lds_byte* pbase = (lds_byte*)smem + RING_BYTES;
-    for (int o = 0; o + wave * 1024 < G.n_params * 4; o += 8192)        // 8 waves x 1 KB per pass; n_params % 1024 == 0
+    for (int o = 0; o + wave * 1024 < G.n_params * 4; o += WAVES * 1024)  // WAVES x 1 KB per pass; n_params % 1024 == 0
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(
                                              reinterpret_cast<const unsigned char*>(G.params) + o + tid * 16),
                                          (__attribute__((address_space(3))) void*)(pbase + o + wave * 1024), 16, 0, 0);
@@ -424,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void ranker_x3b_kernel(Program G, Input in,
     lds_cfloat* pb = reinterpret_cast<lds_cfloat*>(pbase) + 4 * g;
 
     Ring ring;
+    const unsigned long long t_begin = (DBG & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
     ring.start(G.stream, G.total_chunks, (lds_byte*)smem, wave, lane);
 
     f32x4 x[16];
@@ -457,6 +514,13 @@ __global__ __launch_bounds__(512, 2) void ranker_x3b_kernel(Program G, Input in,
     }
     if (x_out != nullptr && row_ok) store_rows(x, x_out + row * ld_xout, g);
     ring.drain();
+    if ((DBG & 16) && lane == 0) {            // diagnostic build: cycle stamps into the unused tail of the logits buffer
+        float* dbg = logits + 3 * ld_logits + ((long long)blockIdx.x * WAVES + wave) * 4;
+        dbg[0] = (float)(__builtin_amdgcn_s_memtime() - t_begin);
+        dbg[1] = (DBG & 32) ? (float)ring.t_lds : (float)ring.t_wait;
+        dbg[2] = (DBG & 32) ? (float)ring.t_cal : (float)ring.t_bar;
+        dbg[3] = (float)ring.t_dma;
+    }
 }
 
 }  // namespace x3b

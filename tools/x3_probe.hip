@@ -6,17 +6,23 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "../movie-recommender-demo_amd/csrc/rowowner.hpp"
 #include "../movie-recommender-demo_amd/csrc/rowowner16.hpp"
 #ifndef AMDREC_X3_VARIANT
 #define AMDREC_X3_VARIANT 32
 #endif
+#ifndef PROBE_PARAM_FLOATS
+#define PROBE_PARAM_FLOATS x3::PARAM_FLOATS
+#endif
 #if AMDREC_X3_VARIANT == 16
 #define KERNEL x3b::ranker_x3b_kernel
-#define NTHREADS 512
+#define NTHREADS (64 * x3b::WAVES)
+#define ROWS_WG (16 * x3b::WAVES)
 #else
 #define KERNEL x3::ranker_x3_kernel
 #define NTHREADS 256
+#define ROWS_WG 128
 #endif
 using namespace amdrec;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -31,11 +37,12 @@ int main(int argc, char** argv) {
         const uint16_t e = 15 + 4 + rand() % 8;
         v = (uint16_t)(((rand() & 1) << 15) | (e << 10) | (rand() & 0x3ff));
     }
+    if (argc > 2 && atoi(argv[2]) == 1) std::fill(st.begin(), st.end(), (uint16_t)0);     // zero weights: data-dependent power (DVFS) check
     uint16_t* dstream; float *dX, *dpar, *dscratch, *dlog;
     CK(hipMalloc(&dstream, st.size() * 2));
     CK(hipMemcpy(dstream, st.data(), st.size() * 2, hipMemcpyHostToDevice));
     std::vector<float> X((size_t)rows * 256);
-    for (auto& v : X) v = (float)(rand() % 2001 - 1000) / 500.f;
+    for (auto& v : X) v = (argc > 2 && atoi(argv[2]) == 2) ? 0.f : (float)(rand() % 2001 - 1000) / 500.f;   // 2: zero activations
     CK(hipMalloc(&dX, X.size() * 4));
     CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> par(x3::PARAM_FLOATS, 0.01f);     // the blob: every parameter 0.01 except "gamma" = 1 at 2048..4095
@@ -59,26 +66,38 @@ int main(int argc, char** argv) {
     x3::Phase& H = G.ph[n++];
     H.type = x3::PH_HEADS; H.n_steps = h1 / 32; H.n_tasks = T; H.b1 = 0; H.sw1 = sw; H.sw2 = sw; H.hn = 8.f; H.hb = 0.01f;
     for (int t = 0; t < T; ++t) { G.hb2[t] = 0; G.hw3[t] = 64; G.hb3[t] = 128; }
-    G.params = dpar; G.n_params = x3::PARAM_FLOATS;
+    G.params = dpar; G.n_params = PROBE_PARAM_FLOATS;
     G.n_phases = n; G.total_chunks = (int)chunks; G.stream = (const unsigned char*)dstream;
     x3::Input in{};
     in.X = dX; in.ldx = 256;
-    CK(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
-    const unsigned grid = (unsigned)((rows + 127) / 128);
+    CK(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + PROBE_PARAM_FLOATS * 4));
+    const unsigned grid = (unsigned)((rows + ROWS_WG - 1) / ROWS_WG);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(NTHREADS), x3::RING_BYTES + x3::PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(NTHREADS), x3::RING_BYTES + PROBE_PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
     CK(hipDeviceSynchronize());
     const int reps = 10;
     CK(hipEventRecord(e0));
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(NTHREADS), x3::RING_BYTES + x3::PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(NTHREADS), x3::RING_BYTES + PROBE_PARAM_FLOATS * 4, 0, G, in, rows, dscratch, (float*)nullptr, 0ll, dlog, rows);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
+    if (AMDREC_X3_DBG & 16) {              // cycle stamps of every wave (rowowner16.hpp, DBG & 16)
+        std::vector<float> lg((size_t)rows * 4);
+        CK(hipMemcpy(lg.data(), dlog, lg.size() * 4, hipMemcpyDeviceToHost));
+        const long long nw = (long long)grid * (NTHREADS / 64);
+        double tot = 0, w = 0, b = 0, d = 0;
+        for (long long i = 0; i < nw; ++i) {
+            const float* p = &lg[3 * rows + i * 4];
+            tot += p[0]; w += p[1]; b += p[2]; d += p[3];
+        }
+        printf("per wave (cycles, mean of %lld waves): total %.0f  dma-wait %.0f (%.1f%%)  barrier %.0f (%.1f%%)  dma-issue %.0f (%.1f%%)  rest %.0f\n",
+               nw, tot / nw, w / nw, 100 * w / tot, b / nw, 100 * b / tot, d / nw, 100 * d / tot, (tot - w - b - d) / nw);
+    }
     const double flop = 2.0 * rows * (L * (65536.0 + 2 * 262144.0) + C * 65536.0 + T * (65536.0 + 16384.0 + 64.0));
     printf("variant=%d DBG=%d rows=%lld: %.3f ms  %.1f TF fp32-equivalent  (%.3f of 833 TF)\n", AMDREC_X3_VARIANT, AMDREC_X3_DBG, rows, ms, flop / ms / 1e9,
            flop / ms / 1e9 / 833.3);
