@@ -43,9 +43,6 @@ using x3::DEPTH;
 #ifndef AMDREC_X3B_WAVES
 #define AMDREC_X3B_WAVES 8
 #endif
-#ifndef AMDREC_X3B_STAGGER
-#define AMDREC_X3B_STAGGER 1
-#endif
 constexpr int WAVES = AMDREC_X3B_WAVES, ROWS_PER_WAVE = 16, ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
 constexpr int DMA_PER_WAVE = CHUNK_FRAGS / WAVES;     // 2 fragment sets per wave and chunk
 
@@ -79,12 +76,6 @@ struct Ring {
                                              (__attribute__((address_space(3))) void*)(dst + u * FRAG_BYTES), 16, 0, 0);
         ++issued;
     }
-    // `late` waves (the second wave of each SIMD) issue their share of the next chunk's DMA two groups into the chunk
-    // instead of right behind the barrier: a DMA piece blocks its wave for ~100 cycles (in-kernel stamps: 13 % of a
-    // wave's time), and with both waves of a SIMD blocked at the same moment the matrix pipe idles; staggered, one
-    // multiplies while the other issues.  The counted vmcnt wait is unchanged: a wave still has issued exactly one more
-    // chunk by the time it certifies the next.
-    bool late;
     __device__ __forceinline__ void certify_next() {
         if (DBG & 16) {
             const unsigned long long a = __builtin_amdgcn_s_memtime();
@@ -92,23 +83,13 @@ struct Ring {
             const unsigned long long b = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
             const unsigned long long c = __builtin_amdgcn_s_memtime();
-            if (!late) issue();
+            issue();
             const unsigned long long d = __builtin_amdgcn_s_memtime();
             t_wait += b - a; t_bar += c - b; t_dma += d - c;
             return;
         }
         if (!(DBG & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * (DEPTH - 1)) : "memory");
         if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
-        if (!late) issue();
-    }
-    __device__ __forceinline__ void late_issue() {
-        if (!late) return;
-        if (DBG & 16) {
-            const unsigned long long c = __builtin_amdgcn_s_memtime();
-            issue();
-            t_dma += __builtin_amdgcn_s_memtime() - c;
-            return;
-        }
         issue();
     }
     __device__ __forceinline__ void start(const unsigned char* stream, int total_chunks, lds_byte* lds, int wave, int lane) {
@@ -120,7 +101,6 @@ struct Ring {
         slot = -1;
         cbase = lds_rd;
         gdyn = 0;
-        late = AMDREC_X3B_STAGGER && wave >= WAVES / 2;
         t_wait = t_bar = t_dma = t_lds = 0;
         t_cal = 0;
         if (DBG & 32) {
@@ -148,7 +128,6 @@ struct Ring {
     __device__ __forceinline__ void read4(f16x8 (&f)[4]) {
         static_assert(G >= 0 && G < 4 && CHUNK_FRAGS == 16, "four groups of four fragment sets per chunk");
         if (G == 0) next_chunk();
-        if (G == 2) late_issue();
         if (DBG & 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(f[u]));
@@ -162,7 +141,6 @@ struct Ring {
     __device__ __forceinline__ void align() { gdyn = 0; }
     __device__ __forceinline__ void read4_dyn(f16x8 (&f)[4]) {
         if (gdyn == 0) next_chunk();
-        if (gdyn == 2) late_issue();
         const lds_byte* a = cbase + (uint32_t)gdyn * (4 * FRAG_BYTES);
         if (DBG & 4) {
 #pragma unroll
