@@ -319,7 +319,9 @@ def main():
             roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         "peak_note": ("fp32-equivalent FLOPs (2*M*N*K of every GEMM of the chain) against dense fp16 MFMA peak "
-                                      f"/ 3 products = executed-MFMA utilisation; the fp32 MFMA peak is {FP32_PEAK_TFLOPS}") if x3
+                                      f"/ 3 products = executed-MFMA utilisation; the fp32 MFMA peak is {FP32_PEAK_TFLOPS}; "
+                                      "the peak is priced at 2.4 GHz - on realistic operands the chip holds ~2.0 GHz on this kernel "
+                                      "(power-limited: profiles/r02_x3_cycle_stamps_and_dvfs.log), where the bound is ~694") if x3
                         else (("fp32-equivalent FLOPs (2*M*N*K) against dense bf16 MFMA peak / 6 products; "
                                f"the fp32 MFMA peak is {FP32_PEAK_TFLOPS}") if x6 else "fp32 MFMA peak"),
                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
