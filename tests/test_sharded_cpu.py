@@ -175,6 +175,37 @@ def test_short_shard_lists_are_proven_exact_or_repeated(shard_k, sort_corpus, ex
             assert ids[j].tolist() == r["ad_ids"]
 
 
+@pytest.mark.timeout(300)
+def test_four_rank_short_lists_all_to_all():
+    """world 4 (two users per rank, all-to-all): rank > 1 offsets, packing and the short-list merge; whether the 24-entry
+    lists are proven or the step is repeated with full lists, the result is the unsharded oracle's."""
+    world, Bn = 4, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, Bn, "all_to_all", 24, False)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(Bn)
+    oidx = oracle.search.FlatIndex(256)
+    oidx.add(corpus)
+    ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
+    covered = []
+    for rank, q0, ids, sc, cand, cs, used_k, shard_k_after in res:
+        assert (q0, len(ids)) == user_slice(Bn, rank, world) and used_k == 24 and shard_k_after in (24, None)
+        for j in range(len(ids)):
+            r = ref[q0 + j]
+            assert np.array_equal(cand[j], r["candidate_ids"]) and np.array_equal(cs[j], r["candidate_scores"])
+            assert ids[j].tolist() == r["ad_ids"]
+            covered.append(q0 + j)
+    assert covered == list(range(Bn))
+    assert len({r[7] for r in res}) == 1                              # every rank took the same decision
+
+
 def test_short_list_length_and_merge_rule():
     from amdrec.sharded import short_list_k
     assert [short_list_k(500, w) for w in (1, 2, 4, 8)] == [500, 352, 192, 128]
