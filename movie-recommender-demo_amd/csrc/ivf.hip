@@ -147,7 +147,12 @@ __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
     gemm_block<ShapeIvf>(lp, lq, epi, ksteps, (y - qt_prefix[l]) * ShapeIvf::BP, row0, smem);
 }
 
-// k largest of keys[q][0..n_q) -> sorted (score desc, position asc); fewer than k -> padded (-inf, -1)
+// k largest of keys[q][0..n_q) -> sorted (score desc, position asc); fewer than k -> padded (-inf, -1).
+// The k-th largest SCORE is found by a 3-pass radix select over the keys' high words (11 + 11 + 10 bits); every key at or
+// above it is then gathered (the keys above it plus its ties) and the bitonic sort of the full 64-bit keys settles the
+// ties by position.  Four reads of the pool instead of the seven of a select over the whole 64-bit key; only when the
+// boundary score has so many ties that the gather would not fit (k + ties > 2048) does the kernel fall back to that
+// 6-pass select of the exact k-th key.
 __global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long long* keys, long long pool_ld,
                                                          const long long* n_pool, int k, float* outD,
                                                          long long* outI) {
@@ -159,13 +164,47 @@ __global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long lon
     const int tid = threadIdx.x;
     const long long n = n_pool[q];
     const unsigned long long* row = keys + q * pool_ld;
-    unsigned long long kstar = 0ull;          // select everything by default (n <= k)
+    unsigned long long kstar = 0ull;          // gather everything by default (n <= k)
     if (n > k) {
+        uint32_t prefix = 0u, pmask = 0u;
+        int rr = k;
+        const int shifts[3] = {21, 10, 0};
+        const int bits[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            for (int i = tid; i < 2048; i += 512) hist[i] = 0;
+            __syncthreads();
+            const uint32_t bm = (1u << bits[pass]) - 1u;
+            for (long long i = tid; i < n; i += 512) {
+                const uint32_t hi = (uint32_t)(row[i] >> 32);
+                if ((hi & pmask) == prefix) atomicAdd(&hist[(hi >> shifts[pass]) & bm], 1);
+            }
+            __syncthreads();
+            const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);   // always found: n > k >= rr
+            prefix |= (uint32_t)bin << shifts[pass];
+            pmask |= bm << shifts[pass];
+        }
+        kstar = (unsigned long long)prefix << 32;      // every key whose score is the k-th largest score or better
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (tid == 0) count = 0;
+        for (int i = tid; i < 2048; i += 512) buf[i] = 0ull;
+        __syncthreads();
+        for (long long i = tid; i < n; i += 512) {
+            const unsigned long long key = row[i];
+            if (key >= kstar) {
+                const int pos = atomicAdd(&count, 1);
+                if (pos < 2048) buf[pos] = key;
+            }
+        }
+        __syncthreads();
+        if (count <= 2048 || attempt == 1) break;        // block-uniform
+        // too many ties at the boundary score: the exact k-th KEY by a 6-pass select over all 64 bits, then exactly k pass
         unsigned long long prefix = 0ull, pmask = 0ull;
         int rr = k;
         const int shifts[6] = {53, 42, 31, 20, 9, 0};
         const int bits[6] = {11, 11, 11, 11, 11, 9};
         for (int pass = 0; pass < 6; ++pass) {
+            __syncthreads();
             for (int i = tid; i < 2048; i += 512) hist[i] = 0;
             __syncthreads();
             const unsigned long long bm = (1ull << bits[pass]) - 1;
@@ -174,27 +213,18 @@ __global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long lon
                 if ((key & pmask) == prefix) atomicAdd(&hist[(int)((key >> shifts[pass]) & bm)], 1);
             }
             __syncthreads();
-            const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);   // always found: n > k >= rr
+            const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);
             prefix |= (unsigned long long)bin << shifts[pass];
             pmask |= bm << shifts[pass];
         }
-        kstar = prefix;                        // the k-th largest key itself
+        kstar = prefix;
+        __syncthreads();
     }
-    if (tid == 0) count = 0;
+    const int have_all = count < 2048 ? count : 2048;
     int P = 2;
-    while (P < k) P <<= 1;
-    for (int i = tid; i < P; i += 512) buf[i] = 0ull;
-    __syncthreads();
-    for (long long i = tid; i < n; i += 512) {
-        const unsigned long long key = row[i];
-        if (key >= kstar) {
-            const int pos = atomicAdd(&count, 1);
-            if (pos < 2048) buf[pos] = key;    // exactly min(n, k) keys pass (keys are unique)
-        }
-    }
-    __syncthreads();
+    while (P < have_all) P <<= 1;             // >= k whenever n >= k (k <= 2048)
     bitonic_desc(buf, P);
-    const int have = count < k ? count : k;
+    const int have = have_all < k ? have_all : k;
     write_result(buf, have, k, q, outD, outI, 0);
 }
 

@@ -173,3 +173,34 @@ def test_ivf_pipeline_captures_in_a_hip_graph():
         out = g(uc, un)
         torch.cuda.synchronize()
         assert torch.equal(out["ad_ids"], ids) and torch.equal(out["scores"], sc)
+
+
+@pytest.mark.parametrize("copies", [1500, 6000])
+def test_ivf_select_boundary_ties(copies):
+    """`copies` identical rows tie at the k-th score (k = 500): 1500 ties still fit the select's gather (k-th SCORE by a
+    3-pass radix select, ties settled by the 64-bit sort), 6000 take its fallback (6-pass select of the exact k-th key).
+    Either way the result is the lowest positions among the tied rows, as the oracle's order rule says."""
+    from amdrec.index import FAISSIndex, flat_search
+    n, nlist, nprobe, k, nq = 20_000, 32, 32, 500, 3
+    xb = _clustered(n, 256, 10, 5)
+    rng = np.random.default_rng(6)
+    where = np.sort(rng.choice(n, copies, replace=False))
+    xb[where] = xb[where[0]]                                   # identical rows, scattered over the corpus
+    xq = np.stack([xb[where[0]] + 0.5 * _clustered(1, 256, 10, 7 + i)[0] for i in range(nq)])
+    # a few hundred rows score above the copies for every query, so the copies straddle rank 500
+    idx = FAISSIndex(256, index_type="IVF", nlist=nlist, nprobe=nprobe)       # all lists probed: == exact search
+    idx.add(xb)
+    ids, D = idx.search(xq, k)
+    xbn, xqn = oracle.search.normalize_l2(xb), oracle.search.normalize_l2(xq)
+    cs = torch.empty((nq, nprobe), dtype=torch.float32, device="cuda")
+    pr = torch.empty((nq, nprobe), dtype=torch.int64, device="cuda")
+    flat_search(idx._ivf.centroids, nlist, torch.from_numpy(xqn).cuda(), nprobe, cs, pr)
+    rD, rI = oracle.search.ivf_search(xbn, idx._ivf.assign.cpu().numpy(), idx._ivf.centroids.cpu().numpy(), xqn, k, nprobe,
+                                      probes=pr.cpu().numpy())
+    tied = set(where.tolist())
+    for q in range(nq):
+        got_t = [i for i in ids[q] if int(i) in tied]
+        ref_t = [i for i in rI[q] if int(i) in tied]
+        assert 0 < len(ref_t) < copies                          # the copies do straddle the boundary
+        assert got_t == ref_t == sorted(ref_t)                  # the tied rows that made it: the lowest positions, in order
+    oracle.search.check_topk(rD, rI, D, ids, tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
