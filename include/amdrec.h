@@ -78,13 +78,14 @@ int amdrec_ivf_scan(const float* lists, int64_t ld, int dim, const int64_t* row_
                     const int64_t* probes, const int64_t* pool_base, int nprobe, uint64_t* pool_keys,
                     int64_t pool_ld, int64_t pos_offset, void* stream);
 /* Batched form of step 3: the (query, probe) pairs sorted by list (pair_query / pair_probe, group_off
- * [nlist+1]); qtile_prefix[nlist+1] = prefix sum of ceil(group size / 64); qtile_bound >= qtile_prefix[nlist]
- * (a host-side upper bound, e.g. pairs/64 + nlist, <= 65535).  Every list is read once per 64-query group
- * by an fp32-MFMA GEMM tile instead of once per probing query.  Same pool layout and keys as amdrec_ivf_scan. */
+ * [nlist+1]); qtile_prefix[nlist+1] = prefix sum of ceil(group size / qtile); qtile_bound >= qtile_prefix[nlist]
+ * (a host-side upper bound, e.g. pairs/qtile + nlist, <= 65535).  Every list is read once per qtile-query group
+ * by an fp32-MFMA GEMM tile instead of once per probing query; qtile = 64, or 32 when the groups are sparse (few probing
+ * queries per list) - the value given to amdrec_ivf_group.  Same pool layout and keys as amdrec_ivf_scan. */
 int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, const int64_t* row_pos,
                             const int64_t* list_off, int nlist, int64_t max_list_rows, const float* queries,
                             int64_t ld_queries, const int64_t* group_off, const int64_t* qtile_prefix,
-                            int64_t qtile_bound, const int64_t* pair_query, const int64_t* pair_probe,
+                            int64_t qtile_bound, int qtile, const int64_t* pair_query, const int64_t* pair_probe,
                             const int64_t* pool_base, int nprobe, uint64_t* pool_keys, int64_t pool_ld,
                             int64_t pos_offset, void* stream);
 int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count /*[nq]*/,
@@ -96,7 +97,8 @@ int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t*
  * does not influence any result).  workspace: >= 4*(nlist+1) + 4*nq*nprobe + 512 bytes. */
 int amdrec_ivf_group(const int64_t* probes, int64_t nq, int nprobe, int nlist, const int64_t* list_len /*[nlist]*/,
                      int64_t* pool_base, int64_t* pool_count, int64_t* pair_query, int64_t* pair_probe,
-                     int64_t* group_off, int64_t* qtile_prefix, void* workspace, size_t workspace_bytes, void* stream);
+                     int64_t* group_off, int64_t* qtile_prefix, int qtile /*32 or 64*/, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* Index build (faiss IndexIVFFlat.train / .add behind FAISSIndex.train / .add, faiss_retrieval.py:83-95, :118).
  * amdrec_ivf_assign: assign[r] = arg max_c <x[r], centroids[c]> (the IndexFlatIP quantizer; ties -> lower c;

@@ -30,7 +30,9 @@ MAX_POINTS_PER_CENTROID = 256
 SEED = 1234
 POOL_BYTES = 2 << 30           # candidate-pool workspace per query chunk
 GROUPED_MIN_QUERIES = 16       # batches at least this large scan list-major (every list read once per 64 queries)
-QTILE = 64                     # queries per grouped-scan tile (ShapeIvf::BP)
+QTILE = 64                     # queries per grouped-scan tile (ShapeIvf::BP) ...
+QTILE_SPARSE = 32              # ... or 32 (ShapeIvf32) when fewer than SPARSE_PAIRS_PER_LIST queries probe a list on average
+SPARSE_PAIRS_PER_LIST = 24
 
 
 def _normalize(x):
@@ -126,8 +128,9 @@ class IVFState:
         pool_ld = max(1, nprobe * max_len)
         chunk = max(1, min(nq, 65535, POOL_BYTES // (pool_ld * 8)))
         grouped = nq >= GROUPED_MIN_QUERIES
-        if grouped:                                   # one launch needs pairs/64 + nlist <= 65535 query tiles
-            chunk = max(1, min(chunk, ((65535 - self.nlist) * QTILE) // nprobe))
+        qtile = QTILE_SPARSE if min(chunk, nq) * nprobe < SPARSE_PAIRS_PER_LIST * self.nlist else QTILE
+        if grouped:                                   # one launch needs pairs/qtile + nlist <= 65535 query tiles
+            chunk = max(1, min(chunk, ((65535 - self.nlist) * qtile) // nprobe))
         # one workspace: [candidate pool | grouping scratch | pair arrays and offsets]
         pool_bytes = (chunk * pool_ld * 8 + 255) // 256 * 256
         grp_bytes = ((self.nlist + 1) * 4 + 255) // 256 * 256 + (chunk * nprobe * 4 + 255) // 256 * 256
@@ -144,12 +147,12 @@ class IVFState:
             m = min(chunk, nq - s)
             _lib.check(lib.amdrec_ivf_group(_lib.ptr(probes[s:]), m, nprobe, self.nlist, _lib.ptr(lens), _lib.ptr(base[s:]),
                                             _lib.ptr(n_pool[s:]), _lib.ptr(pair_q), _lib.ptr(pair_p), _lib.ptr(goff),
-                                            _lib.ptr(qtp), _lib.ptr(grp), grp.numel(), st))
+                                            _lib.ptr(qtp), qtile, _lib.ptr(grp), grp.numel(), st))
             if grouped:
-                bound = (m * nprobe) // QTILE + self.nlist
+                bound = (m * nprobe) // qtile + self.nlist
                 _lib.check(lib.amdrec_ivf_scan_grouped(
                     _lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off), self.nlist, max_len,
-                    _lib.ptr(q[s:]), q.stride(0), _lib.ptr(goff), _lib.ptr(qtp), bound, _lib.ptr(pair_q),
+                    _lib.ptr(q[s:]), q.stride(0), _lib.ptr(goff), _lib.ptr(qtp), bound, qtile, _lib.ptr(pair_q),
                     _lib.ptr(pair_p), _lib.ptr(base[s:]), nprobe, _lib.ptr(ws), pool_ld, pos_offset, st))
             else:
                 _lib.check(lib.amdrec_ivf_scan(_lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off),

@@ -121,8 +121,11 @@ struct EpiIvfKeys {
     }
 };
 
-using ShapeIvf = Shape<2, 2, 1, 4>;   // 64 queries x 256 list rows per workgroup
+using ShapeIvf = Shape<2, 2, 1, 4>;     // 64 queries x 256 list rows per workgroup
+using ShapeIvf32 = Shape<1, 4, 1, 2>;   // 32 queries x 256 list rows: for sparse groups (few probing queries per list: 512 x 64
+                                        // probes over 4096 lists is 8 per list, a 64-query tile would be 12 % full)
 
+template <class ShapeIvf>
 __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
     const float* xs, long long ld, int d, int ksteps, const long long* spos, const long long* list_off,
     const float* Q, long long ldq, const long long* goff, const long long* qt_prefix, int nlist,
@@ -330,14 +333,15 @@ __global__ void ivf_pool_layout_kernel(const long long* probes, long long m, int
     }
     n_pool[q] = run;
 }
-// exclusive scans over the lists: group offsets and 64-query-tile offsets (one block)
-__global__ __launch_bounds__(1024) void ivf_group_prefix_kernel(const int* cnt, int nlist, long long* goff, long long* qtp) {
+// exclusive scans over the lists: group offsets and query-tile offsets (tiles of qtile queries; one block)
+__global__ __launch_bounds__(1024) void ivf_group_prefix_kernel(const int* cnt, int nlist, int qtile, long long* goff,
+                                                                 long long* qtp) {
     __shared__ long long sa[1024], sb[1024];
     const int tid = threadIdx.x;
     const int per = (nlist + 1023) / 1024;
     const int lo = tid * per, hi = (lo + per < nlist) ? lo + per : nlist;
     long long a = 0, b = 0;
-    for (int l = lo; l < hi; ++l) { a += cnt[l]; b += (cnt[l] + 63) / 64; }
+    for (int l = lo; l < hi; ++l) { a += cnt[l]; b += (cnt[l] + qtile - 1) / qtile; }
     sa[tid] = a; sb[tid] = b;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {                  // Hillis-Steele inclusive scan of the 1024 partials
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(1024) void ivf_group_prefix_kernel(const int* cnt, 
     long long ra = sa[tid] - a, rb = sb[tid] - b;         // exclusive prefix of this thread's range
     for (int l = lo; l < hi; ++l) {
         goff[l] = ra; qtp[l] = rb;
-        ra += cnt[l]; rb += (cnt[l] + 63) / 64;
+        ra += cnt[l]; rb += (cnt[l] + qtile - 1) / qtile;
     }
     if (tid == 1023) { goff[nlist] = sa[1023]; qtp[nlist] = sb[1023]; }
 }
@@ -439,9 +443,10 @@ extern "C" int amdrec_ivf_kmeans_step(const float* x, int64_t rows, int64_t ld, 
 
 extern "C" int amdrec_ivf_group(const int64_t* probes, int64_t nq, int nprobe, int nlist, const int64_t* list_len,
                                 int64_t* pool_base, int64_t* pool_count, int64_t* pair_query, int64_t* pair_probe,
-                                int64_t* group_off, int64_t* qtile_prefix, void* workspace, size_t workspace_bytes,
-                                void* stream) {
+                                int64_t* group_off, int64_t* qtile_prefix, int qtile, void* workspace,
+                                size_t workspace_bytes, void* stream) {
     REQUIRE(nprobe >= 1 && nlist >= 1 && nlist <= (1 << 20), "bad nlist/nprobe");
+    REQUIRE(qtile == 32 || qtile == 64, "qtile must be 32 or 64");
     if (nq <= 0) return AMDREC_OK;
     REQUIRE(nq * (int64_t)nprobe < (1ll << 31), "too many (query, probe) pairs for one call");
     REQUIRE(probes && list_len && pool_base && pool_count && pair_query && pair_probe && group_off && qtile_prefix, "null pointer");
@@ -457,7 +462,8 @@ extern "C" int amdrec_ivf_group(const int64_t* probes, int64_t nq, int nprobe, i
                        (const long long*)probes, npairs, nlist, cnt, rank);
     hipLaunchKernelGGL(ivf_pool_layout_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const long long*)probes,
                        (long long)nq, nprobe, nlist, (const long long*)list_len, (long long*)pool_base, (long long*)pool_count);
-    hipLaunchKernelGGL(ivf_group_prefix_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, (long long*)group_off, (long long*)qtile_prefix);
+    hipLaunchKernelGGL(ivf_group_prefix_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, qtile, (long long*)group_off,
+                       (long long*)qtile_prefix);
     hipLaunchKernelGGL(ivf_group_scatter_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
                        (const long long*)probes, npairs, nprobe, nlist, rank, (const long long*)group_off,
                        (long long*)pair_query, (long long*)pair_probe);
@@ -483,34 +489,57 @@ extern "C" int amdrec_ivf_scan(const float* lists, int64_t ld, int dim, const in
     return AMDREC_OK;
 }
 
+template <class S>
+static hipError_t launch_group_scan(const char* tag, const float* lists, long long ld, int dim, const long long* row_pos,
+                                    const long long* list_off, int nlist, long long max_list_rows, const float* queries,
+                                    long long ld_queries, const long long* group_off, const long long* qtile_prefix,
+                                    long long qtile_bound, const long long* pair_query, const long long* pair_probe,
+                                    const long long* pool_base, int nprobe, unsigned long long* pool_keys, long long pool_ld,
+                                    long long pos_offset, hipStream_t st) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_group_scan_kernel<S>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done.mark();
+    }
+    const unsigned gx = (unsigned)((max_list_rows + S::BQ - 1) / S::BQ);
+    ProfScope prof(tag, 0.0, 0.0, st);
+    hipLaunchKernelGGL(ivf_group_scan_kernel<S>, dim3(gx, (unsigned)qtile_bound), dim3(S::NT), S::LDS_BYTES, st, lists, ld, dim,
+                       (dim + BK - 1) / BK, row_pos, list_off, queries, ld_queries, group_off, qtile_prefix, nlist, pair_query,
+                       pair_probe, pool_base, nprobe, pool_keys, pool_ld, pos_offset);
+    return hipGetLastError();
+}
+
 extern "C" int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, const int64_t* row_pos,
                                        const int64_t* list_off, int nlist, int64_t max_list_rows,
                                        const float* queries, int64_t ld_queries, const int64_t* group_off,
-                                       const int64_t* qtile_prefix, int64_t qtile_bound, const int64_t* pair_query,
-                                       const int64_t* pair_probe, const int64_t* pool_base, int nprobe,
-                                       uint64_t* pool_keys, int64_t pool_ld, int64_t pos_offset, void* stream) {
+                                       const int64_t* qtile_prefix, int64_t qtile_bound, int qtile,
+                                       const int64_t* pair_query, const int64_t* pair_probe, const int64_t* pool_base,
+                                       int nprobe, uint64_t* pool_keys, int64_t pool_ld, int64_t pos_offset, void* stream) {
     REQUIRE(dim >= 4 && dim % 4 == 0 && dim <= 2048, "dim=%d must be a multiple of 4 in [4,2048]", dim);
     REQUIRE(nlist >= 1 && nprobe >= 1, "bad nlist/nprobe");
+    REQUIRE(qtile == 32 || qtile == 64, "qtile must be 32 or 64 (the value given to amdrec_ivf_group)");
     if (qtile_bound <= 0 || max_list_rows <= 0) return AMDREC_OK;
     REQUIRE(qtile_bound <= 65535, "too many (list, query-tile) groups for one launch: chunk the queries");
     REQUIRE(lists && row_pos && list_off && queries && group_off && qtile_prefix && pair_query && pair_probe &&
                 pool_base && pool_keys, "null pointer");
     REQUIRE(ld % 4 == 0 && ld >= dim && ld_queries >= dim && ld_queries % 4 == 0, "bad leading dimension");
-    static PerDeviceOnce attr_done;
-    if (attr_done.pending()) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_group_scan_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ShapeIvf::LDS_BYTES));
-        attr_done.mark();
-    }
-    const unsigned gx = (unsigned)((max_list_rows + ShapeIvf::BQ - 1) / ShapeIvf::BQ);
-    ProfScope prof("ivf_scan_grouped_64x256", 0.0, 0.0, reinterpret_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(ivf_group_scan_kernel, dim3(gx, (unsigned)qtile_bound), dim3(ShapeIvf::NT), ShapeIvf::LDS_BYTES,
-                       reinterpret_cast<hipStream_t>(stream), lists, (long long)ld, dim, (dim + BK - 1) / BK,
-                       (const long long*)row_pos, (const long long*)list_off, queries, (long long)ld_queries,
-                       (const long long*)group_off, (const long long*)qtile_prefix, nlist,
-                       (const long long*)pair_query, (const long long*)pair_probe, (const long long*)pool_base, nprobe,
-                       (unsigned long long*)pool_keys, (long long)pool_ld, (long long)pos_offset);
-    HIP_TRY(hipGetLastError());
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (qtile == 64)
+        e = launch_group_scan<ShapeIvf>("ivf_scan_grouped_64x256", lists, ld, dim, (const long long*)row_pos,
+                                        (const long long*)list_off, nlist, max_list_rows, queries, ld_queries,
+                                        (const long long*)group_off, (const long long*)qtile_prefix, qtile_bound,
+                                        (const long long*)pair_query, (const long long*)pair_probe, (const long long*)pool_base,
+                                        nprobe, (unsigned long long*)pool_keys, pool_ld, pos_offset, st);
+    else
+        e = launch_group_scan<ShapeIvf32>("ivf_scan_grouped_32x256", lists, ld, dim, (const long long*)row_pos,
+                                          (const long long*)list_off, nlist, max_list_rows, queries, ld_queries,
+                                          (const long long*)group_off, (const long long*)qtile_prefix, qtile_bound,
+                                          (const long long*)pair_query, (const long long*)pair_probe, (const long long*)pool_base,
+                                          nprobe, (unsigned long long*)pool_keys, pool_ld, pos_offset, st);
+    HIP_TRY(e);
     return AMDREC_OK;
 }
 
