@@ -87,7 +87,13 @@ int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, const int64
                             int64_t ld_queries, const int64_t* group_off, const int64_t* qtile_prefix,
                             int64_t qtile_bound, int qtile, const int64_t* pair_query, const int64_t* pair_probe,
                             const int64_t* pool_base, int nprobe, uint64_t* pool_keys, int64_t pool_ld,
-                            int64_t pos_offset, void* stream);
+                            int64_t pos_offset, const float* tau /*or NULL*/, int64_t ld_tau,
+                            int64_t* pool_fill /*[nq] or NULL*/, void* stream);
+/* Filter mode of the grouped scan (tau != NULL): a row's key is kept only if its score >= tau[q * ld_tau], appended to
+ * query q's pool row at pool_fill[q]++ (seeded by the caller with the keys already there; pool_base is not used).
+ * With tau[q] = the k-th score over a SUBSET of the probed lists (a lower bound of the final k-th score) the union of
+ * that subset's keys and the kept rows of the remaining lists contains the exact top-k: amdrec.ivf scans the nearest
+ * eighth of the probes unfiltered, selects, and scans the rest with this filter - the pool shrinks ~5x. */
 int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count /*[nq]*/,
                       int64_t nq, int k, float* out_scores /*[nq][k]*/, int64_t* out_pos /*[nq][k]*/,
                       void* stream);
@@ -95,7 +101,8 @@ int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t*
  * (pool_base[nq][nprobe], pool_count[nq]) and the (query, probe) pairs grouped by list for amdrec_ivf_scan_grouped
  * (pair_query / pair_probe [nq*nprobe], group_off / qtile_prefix [nlist+1]; order inside a group is unspecified - it
  * does not influence any result).  workspace: >= 4*(nlist+1) + 4*nq*nprobe + 512 bytes. */
-int amdrec_ivf_group(const int64_t* probes, int64_t nq, int nprobe, int nlist, const int64_t* list_len /*[nlist]*/,
+int amdrec_ivf_group(const int64_t* probes /*[nq][ld_probes], the first nprobe columns*/, int64_t ld_probes, int64_t nq,
+                     int nprobe, int nlist, const int64_t* list_len /*[nlist]*/,
                      int64_t* pool_base, int64_t* pool_count, int64_t* pair_query, int64_t* pair_probe,
                      int64_t* group_off, int64_t* qtile_prefix, int qtile /*32 or 64*/, void* workspace,
                      size_t workspace_bytes, void* stream);

@@ -37,9 +37,9 @@ _SIGNATURES = {
     "amdrec_flat_search": [_fp, _i64, _i64, _i32, _fp, _i64, _i64, _i32, _i64, _fp, _vp, _vp, _sz, _vp, _vp],
     "amdrec_ivf_scan": [_fp, _i64, _i32, _vp, _vp, _fp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _i64, _vp],
     "amdrec_ivf_scan_grouped": [_fp, _i64, _i32, _vp, _vp, _i32, _i64, _fp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32,
-                                _vp, _i64, _i64, _vp],
+                                _vp, _i64, _i64, _fp, _i64, _vp, _vp],
     "amdrec_ivf_select": [_vp, _i64, _vp, _i64, _i32, _fp, _vp, _vp],
-    "amdrec_ivf_group": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
+    "amdrec_ivf_group": [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
     "amdrec_ivf_assign": [_fp, _i64, _i64, _i32, _fp, _i32, _i64, _vp, _fp, _vp, _sz, _vp],
     "amdrec_ivf_kmeans_workspace": [_i64, _i32, _i32, C.POINTER(_sz)],
     "amdrec_ivf_kmeans_step": [_fp, _i64, _i64, _i32, _fp, _i32, _i64, _vp, _sz, _vp],

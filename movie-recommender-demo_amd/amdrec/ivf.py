@@ -12,6 +12,8 @@ section 8c says, IVF parity is: (i) the scan is exact over the probed lists give
 assignments (tested against the oracle), (ii) recall@k against the Flat result is reported.
 Trainer: spherical Lloyd, max-inner-product assignment (the quantizer is IndexFlatIP), <= 256
 training points per centroid, 10 iterations, seed 1234 (faiss' documented defaults).
+Search = coarse probes -> [nearest eighth of the probes: grouped scan -> select -> tau] -> [other probes: grouped scan keeping
+score >= tau] -> select (exact: tau is the k-th score over a subset of the candidates, hence a lower bound of the final one).
 Sharding: the centroids are SHARED by all ranks (``amdrec.sharded.share_ivf_centroids``); a rank
 files its own rows under them and holds its slice of every list, so the union of the ranks' scans is exactly the
 unsharded scan and the merged top-k is bit-identical to the unsharded IVF result.
@@ -33,6 +35,7 @@ GROUPED_MIN_QUERIES = 16       # batches at least this large scan list-major (ev
 QTILE = 64                     # queries per grouped-scan tile (ShapeIvf::BP) ...
 QTILE_SPARSE = 32              # ... or 32 (ShapeIvf32) when fewer than SPARSE_PAIRS_PER_LIST queries probe a list on average
 SPARSE_PAIRS_PER_LIST = 24
+TWO_PHASE_MIN_PROBES = 16      # from here on the scan is split: nearest probes unfiltered, the rest filtered by their k-th score
 
 
 def _normalize(x):
@@ -143,18 +146,41 @@ class IVFState:
         goff = arr[2 * chunk * nprobe:2 * chunk * nprobe + self.nlist + 1]
         qtp = arr[2 * chunk * nprobe + self.nlist + 1:]
         st = _lib.stream_ptr(self.device)
+
+        def group_and_scan(s, m, col0, ncol, tau=None, fill=None, n_out=None):
+            """(query, probe) pairs of probe columns [col0, col0 + ncol) grouped by list, then the grouped scan of those
+            lists: unfiltered into the per-probe slots of the pool, or (tau, fill) filtered and appended."""
+            qt = QTILE_SPARSE if m * ncol < SPARSE_PAIRS_PER_LIST * self.nlist else QTILE
+            pv = probes[s:, col0:]
+            _lib.check(lib.amdrec_ivf_group(_lib.ptr(pv), nprobe, m, ncol, self.nlist, _lib.ptr(lens), _lib.ptr(base[s:]),
+                                            _lib.ptr(n_out), _lib.ptr(pair_q), _lib.ptr(pair_p), _lib.ptr(goff),
+                                            _lib.ptr(qtp), qt, _lib.ptr(grp), grp.numel(), st))
+            _lib.check(lib.amdrec_ivf_scan_grouped(
+                _lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off), self.nlist, max_len,
+                _lib.ptr(q[s:]), q.stride(0), _lib.ptr(goff), _lib.ptr(qtp), (m * ncol) // qt + self.nlist, qt,
+                _lib.ptr(pair_q), _lib.ptr(pair_p), _lib.ptr(base[s:]), ncol, _lib.ptr(ws), pool_ld, pos_offset,
+                _lib.ptr(tau), 0 if tau is None else tau.stride(0), _lib.ptr(fill), st))
+
+        # Exact two-phase scan (batches that take the grouped scan, >= TWO_PHASE_MIN_PROBES probes): the nearest eighth of
+        # the probes unfiltered -> select -> tau = that subset's k-th score, a LOWER bound of the final k-th score -> the other
+        # probes keep only rows with score >= tau, appended behind the first phase's keys -> the final select.  Same
+        # result as one unfiltered scan of every probe; the pool that is written and selected from shrinks several-fold.
+        two_phase = grouped and nprobe >= TWO_PHASE_MIN_PROBES
+        n_first = max(2, nprobe // 8)
+        scratch_n = torch.empty((chunk,), dtype=torch.int64, device=self.device) if two_phase else None
         for s in range(0, nq, chunk):
             m = min(chunk, nq - s)
-            _lib.check(lib.amdrec_ivf_group(_lib.ptr(probes[s:]), m, nprobe, self.nlist, _lib.ptr(lens), _lib.ptr(base[s:]),
-                                            _lib.ptr(n_pool[s:]), _lib.ptr(pair_q), _lib.ptr(pair_p), _lib.ptr(goff),
-                                            _lib.ptr(qtp), qtile, _lib.ptr(grp), grp.numel(), st))
-            if grouped:
-                bound = (m * nprobe) // qtile + self.nlist
-                _lib.check(lib.amdrec_ivf_scan_grouped(
-                    _lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off), self.nlist, max_len,
-                    _lib.ptr(q[s:]), q.stride(0), _lib.ptr(goff), _lib.ptr(qtp), bound, qtile, _lib.ptr(pair_q),
-                    _lib.ptr(pair_p), _lib.ptr(base[s:]), nprobe, _lib.ptr(ws), pool_ld, pos_offset, st))
+            if two_phase:
+                group_and_scan(s, m, 0, n_first, n_out=n_pool[s:])
+                _lib.check(lib.amdrec_ivf_select(_lib.ptr(ws), pool_ld, _lib.ptr(n_pool[s:]), m, k,
+                                                 _lib.ptr(out_scores[s:]), _lib.ptr(out_pos[s:]), st))
+                group_and_scan(s, m, n_first, nprobe - n_first, tau=out_scores[s:, k - 1], fill=n_pool[s:], n_out=scratch_n)
+            elif grouped:
+                group_and_scan(s, m, 0, nprobe, n_out=n_pool[s:])
             else:
+                _lib.check(lib.amdrec_ivf_group(_lib.ptr(probes[s:]), nprobe, m, nprobe, self.nlist, _lib.ptr(lens),
+                                                _lib.ptr(base[s:]), _lib.ptr(n_pool[s:]), _lib.ptr(pair_q), _lib.ptr(pair_p),
+                                                _lib.ptr(goff), _lib.ptr(qtp), qtile, _lib.ptr(grp), grp.numel(), st))
                 _lib.check(lib.amdrec_ivf_scan(_lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off),
                                                _lib.ptr(q[s:]), m, q.stride(0), _lib.ptr(probes[s:]),
                                                _lib.ptr(base[s:]), nprobe, _lib.ptr(ws), pool_ld, pos_offset, st))

@@ -97,6 +97,11 @@ struct EpiIvfKeys {
     int nprobe;
     unsigned long long* keys;
     long long pool_ld, pos_offset;
+    // filter mode (tau != nullptr): only rows with score >= tau[q * ld_tau] are kept, appended at fill[q]++ (the caller
+    // seeds fill[q] with the keys already in the query's pool row); base / pair_p are not used
+    const float* tau;
+    long long ld_tau;
+    unsigned long long* fill;
     template <class A>
     __device__ void operator()(A& acc, float*) const {
         constexpr int TP = A::TP, TQ = A::TQ;
@@ -108,6 +113,19 @@ struct EpiIvfKeys {
                 const long long jj = acc.p(i, r, lane);          // member of the group (depends on the lane half)
                 if (jj >= g) continue;
                 const long long q = pair_q[jj];
+                if (tau != nullptr) {
+                    const float t = tau[q * ld_tau];
+                    unsigned long long* dst = keys + q * pool_ld;
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) {
+                        const long long row = acc.q(j, lane);
+                        if (row >= list_rows) continue;
+                        float sc = acc.v[i][j][r];
+                        if (!(sc == sc)) sc = -INFINITY;
+                        if (sc >= t) dst[atomicAdd(&fill[q], 1ull)] = make_key(sc, (uint32_t)(spos[row] + pos_offset));
+                    }
+                    continue;
+                }
                 unsigned long long* dst = keys + q * pool_ld + base[q * nprobe + pair_p[jj]];
 #pragma unroll
                 for (int j = 0; j < TQ; ++j) {
@@ -130,7 +148,7 @@ __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
     const float* xs, long long ld, int d, int ksteps, const long long* spos, const long long* list_off,
     const float* Q, long long ldq, const long long* goff, const long long* qt_prefix, int nlist,
     const long long* pair_q, const long long* pair_p, const long long* base, int nprobe, unsigned long long* keys,
-    long long pool_ld, long long pos_offset) {
+    long long pool_ld, long long pos_offset, const float* tau, long long ld_tau, unsigned long long* fill) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long long y = blockIdx.y;
     if (y >= qt_prefix[nlist]) return;
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
     const long long g0 = goff[l], g = goff[l + 1] - g0;
     GatherRows lp{Q, pair_q + g0, g, (int)ldq, d};
     DenseRows lq{xs + r0 * ld, len, (int)ld, d, 30, 1ll << 30};
-    EpiIvfKeys epi{spos + r0, len, pair_q + g0, pair_p + g0, g, base, nprobe, keys, pool_ld, pos_offset};
+    EpiIvfKeys epi{spos + r0, len, pair_q + g0, pair_p + g0, g, base, nprobe, keys, pool_ld, pos_offset, tau, ld_tau, fill};
     gemm_block<ShapeIvf>(lp, lq, epi, ksteps, (y - qt_prefix[l]) * ShapeIvf::BP, row0, smem);
 }
 
@@ -315,19 +333,20 @@ __global__ __launch_bounds__(256) void ivf_finish_centroids_kernel(const long lo
 
 // ---- query-time plumbing, sync-free (replaces torch argsort / bincount / cumsum per search call) ---------------------
 // pool layout of every query + rank of every (query, probe) pair inside its list's group (counting sort, pass 1)
-__global__ void ivf_group_count_kernel(const long long* probes, long long npairs, int nlist, int* cnt, int* rank) {
+__global__ void ivf_group_count_kernel(const long long* probes, long long ldp, int nprobe, long long npairs, int nlist, int* cnt,
+                                       int* rank) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npairs) return;
-    const long long l = probes[i];
+    const long long l = probes[(i / nprobe) * ldp + i % nprobe];
     rank[i] = atomicAdd(&cnt[(l < 0 || l >= nlist) ? nlist : (int)l], 1);
 }
-__global__ void ivf_pool_layout_kernel(const long long* probes, long long m, int nprobe, int nlist, const long long* list_len,
-                                       long long* base, long long* n_pool) {
+__global__ void ivf_pool_layout_kernel(const long long* probes, long long ldp, long long m, int nprobe, int nlist,
+                                       const long long* list_len, long long* base, long long* n_pool) {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= m) return;
     long long run = 0;
     for (int p = 0; p < nprobe; ++p) {
-        const long long l = probes[q * nprobe + p];
+        const long long l = probes[q * ldp + p];
         base[q * nprobe + p] = run;
         run += (l >= 0 && l < nlist) ? list_len[l] : 0;
     }
@@ -357,11 +376,11 @@ __global__ __launch_bounds__(1024) void ivf_group_prefix_kernel(const int* cnt, 
     }
     if (tid == 1023) { goff[nlist] = sa[1023]; qtp[nlist] = sb[1023]; }
 }
-__global__ void ivf_group_scatter_kernel(const long long* probes, long long npairs, int nprobe, int nlist, const int* rank,
-                                         const long long* goff, long long* pair_q, long long* pair_p) {
+__global__ void ivf_group_scatter_kernel(const long long* probes, long long ldp, long long npairs, int nprobe, int nlist,
+                                         const int* rank, const long long* goff, long long* pair_q, long long* pair_p) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npairs) return;
-    const long long l = probes[i];
+    const long long l = probes[(i / nprobe) * ldp + i % nprobe];
     if (l < 0 || l >= nlist) return;
     const long long pos = goff[l] + rank[i];
     pair_q[pos] = i / nprobe;
@@ -441,12 +460,13 @@ extern "C" int amdrec_ivf_kmeans_step(const float* x, int64_t rows, int64_t ld, 
     return AMDREC_OK;
 }
 
-extern "C" int amdrec_ivf_group(const int64_t* probes, int64_t nq, int nprobe, int nlist, const int64_t* list_len,
+extern "C" int amdrec_ivf_group(const int64_t* probes, int64_t ld_probes, int64_t nq, int nprobe, int nlist, const int64_t* list_len,
                                 int64_t* pool_base, int64_t* pool_count, int64_t* pair_query, int64_t* pair_probe,
                                 int64_t* group_off, int64_t* qtile_prefix, int qtile, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     REQUIRE(nprobe >= 1 && nlist >= 1 && nlist <= (1 << 20), "bad nlist/nprobe");
     REQUIRE(qtile == 32 || qtile == 64, "qtile must be 32 or 64");
+    REQUIRE(ld_probes >= nprobe, "ld_probes < nprobe");
     if (nq <= 0) return AMDREC_OK;
     REQUIRE(nq * (int64_t)nprobe < (1ll << 31), "too many (query, probe) pairs for one call");
     REQUIRE(probes && list_len && pool_base && pool_count && pair_query && pair_probe && group_off && qtile_prefix, "null pointer");
@@ -459,13 +479,14 @@ extern "C" int amdrec_ivf_group(const int64_t* probes, int64_t nq, int nprobe, i
     int* rank = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + align_up((size_t)(nlist + 1) * 4, 256));
     HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)(nlist + 1) * 4, st));
     hipLaunchKernelGGL(ivf_group_count_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
-                       (const long long*)probes, npairs, nlist, cnt, rank);
+                       (const long long*)probes, (long long)ld_probes, nprobe, npairs, nlist, cnt, rank);
     hipLaunchKernelGGL(ivf_pool_layout_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const long long*)probes,
-                       (long long)nq, nprobe, nlist, (const long long*)list_len, (long long*)pool_base, (long long*)pool_count);
+                       (long long)ld_probes, (long long)nq, nprobe, nlist, (const long long*)list_len, (long long*)pool_base,
+                       (long long*)pool_count);
     hipLaunchKernelGGL(ivf_group_prefix_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, qtile, (long long*)group_off,
                        (long long*)qtile_prefix);
     hipLaunchKernelGGL(ivf_group_scatter_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
-                       (const long long*)probes, npairs, nprobe, nlist, rank, (const long long*)group_off,
+                       (const long long*)probes, (long long)ld_probes, npairs, nprobe, nlist, rank, (const long long*)group_off,
                        (long long*)pair_query, (long long*)pair_probe);
     HIP_TRY(hipGetLastError());
     return AMDREC_OK;
@@ -495,7 +516,8 @@ static hipError_t launch_group_scan(const char* tag, const float* lists, long lo
                                     long long ld_queries, const long long* group_off, const long long* qtile_prefix,
                                     long long qtile_bound, const long long* pair_query, const long long* pair_probe,
                                     const long long* pool_base, int nprobe, unsigned long long* pool_keys, long long pool_ld,
-                                    long long pos_offset, hipStream_t st) {
+                                    long long pos_offset, const float* tau, long long ld_tau, unsigned long long* fill,
+                                    hipStream_t st) {
     static PerDeviceOnce attr_done;
     if (attr_done.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_group_scan_kernel<S>),
@@ -507,7 +529,7 @@ static hipError_t launch_group_scan(const char* tag, const float* lists, long lo
     ProfScope prof(tag, 0.0, 0.0, st);
     hipLaunchKernelGGL(ivf_group_scan_kernel<S>, dim3(gx, (unsigned)qtile_bound), dim3(S::NT), S::LDS_BYTES, st, lists, ld, dim,
                        (dim + BK - 1) / BK, row_pos, list_off, queries, ld_queries, group_off, qtile_prefix, nlist, pair_query,
-                       pair_probe, pool_base, nprobe, pool_keys, pool_ld, pos_offset);
+                       pair_probe, pool_base, nprobe, pool_keys, pool_ld, pos_offset, tau, ld_tau, fill);
     return hipGetLastError();
 }
 
@@ -516,14 +538,16 @@ extern "C" int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, 
                                        const float* queries, int64_t ld_queries, const int64_t* group_off,
                                        const int64_t* qtile_prefix, int64_t qtile_bound, int qtile,
                                        const int64_t* pair_query, const int64_t* pair_probe, const int64_t* pool_base,
-                                       int nprobe, uint64_t* pool_keys, int64_t pool_ld, int64_t pos_offset, void* stream) {
+                                       int nprobe, uint64_t* pool_keys, int64_t pool_ld, int64_t pos_offset,
+                                       const float* tau, int64_t ld_tau, int64_t* pool_fill, void* stream) {
     REQUIRE(dim >= 4 && dim % 4 == 0 && dim <= 2048, "dim=%d must be a multiple of 4 in [4,2048]", dim);
     REQUIRE(nlist >= 1 && nprobe >= 1, "bad nlist/nprobe");
     REQUIRE(qtile == 32 || qtile == 64, "qtile must be 32 or 64 (the value given to amdrec_ivf_group)");
+    REQUIRE((tau == nullptr) == (pool_fill == nullptr) && (tau == nullptr || ld_tau >= 1), "tau and pool_fill go together");
     if (qtile_bound <= 0 || max_list_rows <= 0) return AMDREC_OK;
     REQUIRE(qtile_bound <= 65535, "too many (list, query-tile) groups for one launch: chunk the queries");
     REQUIRE(lists && row_pos && list_off && queries && group_off && qtile_prefix && pair_query && pair_probe &&
-                pool_base && pool_keys, "null pointer");
+                (pool_base || tau) && pool_keys, "null pointer");
     REQUIRE(ld % 4 == 0 && ld >= dim && ld_queries >= dim && ld_queries % 4 == 0, "bad leading dimension");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
@@ -532,13 +556,15 @@ extern "C" int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, 
                                         (const long long*)list_off, nlist, max_list_rows, queries, ld_queries,
                                         (const long long*)group_off, (const long long*)qtile_prefix, qtile_bound,
                                         (const long long*)pair_query, (const long long*)pair_probe, (const long long*)pool_base,
-                                        nprobe, (unsigned long long*)pool_keys, pool_ld, pos_offset, st);
+                                        nprobe, (unsigned long long*)pool_keys, pool_ld, pos_offset, tau, (long long)ld_tau,
+                                        (unsigned long long*)pool_fill, st);
     else
         e = launch_group_scan<ShapeIvf32>("ivf_scan_grouped_32x256", lists, ld, dim, (const long long*)row_pos,
                                           (const long long*)list_off, nlist, max_list_rows, queries, ld_queries,
                                           (const long long*)group_off, (const long long*)qtile_prefix, qtile_bound,
                                           (const long long*)pair_query, (const long long*)pair_probe, (const long long*)pool_base,
-                                          nprobe, (unsigned long long*)pool_keys, pool_ld, pos_offset, st);
+                                          nprobe, (unsigned long long*)pool_keys, pool_ld, pos_offset, tau, (long long)ld_tau,
+                                        (unsigned long long*)pool_fill, st);
     HIP_TRY(e);
     return AMDREC_OK;
 }
