@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child process
+per GPU, spawned before this process imports torch or touches the GPU; the children are fresh interpreters, nothing
+re-execs); under torchrun the ranks are torchrun's.  A world that differs from --gpus exits non-zero.
+
 Workload (BASELINE.json metric / configs[2]): synthetic corpus of 1 000 000 ads,
 d = 256 (randn rows L2-normalised, seed 1234, the reference benchmark's distribution
 faiss_retrieval.py:390), per-ad categorical table ad_cat[1M,20], seeded random-init two-tower
@@ -27,11 +31,78 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "movie-recommender-demo_amd"))
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-users", type=int, default=192)
+    ap.add_argument("--sweep", action="store_true", help="also print the end-to-end latency sweep by batch (stderr)")
+    ap.add_argument("--no-search-sweep", action="store_true",
+                    help="skip the search-only B sweep that fills the line's `search.sweep` (< 1 s)")
+    ap.add_argument("--corpus", choices=["random", "clustered"], default=None,
+                    help="synthetic corpus: randn unit rows (the reference benchmark's, default for flat) or a "
+                         "clustered one (default for ivf: an inverted file needs structure to exploit)")
+    ap.add_argument("--full-lists", action="store_true",
+                    help="N > 1: every shard sends its full top-500 (default: short lists with a proof of exactness)")
+    ap.add_argument("--ads", type=int, default=N_ADS, help="corpus size (configs[3]: 10000000)")
+    ap.add_argument("--index", choices=["flat", "ivf"], default="flat", help="configs[4]: ivf")
+    ap.add_argument("--nlist", type=int, default=4096, help="IVF lists of the coarse quantizer shared by all ranks (whole corpus)")
+    ap.add_argument("--nprobe", type=int, default=64, help="IVF probes per query (every rank scans its slice of each probed list)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="form the world (launcher, rendezvous, world-size checks), print a stub line with n_gpus and "
+                         "exit without touching a GPU: the CPU test of the N > 1 launch path")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start N ranks of this same script, one per GPU, and wait.
+    Runs BEFORE torch is imported: this process never initialises the GPU, and each child is a fresh interpreter
+    (subprocess: fork + exec of a process that holds no HIP state), so nothing that owns a GPU context ever execs.
+    stdout / stderr are inherited: rank 0's JSON line is this process's JSON line.  Exit code = the first failing
+    rank's (the others are terminated by PID), 0 when every rank exits 0."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AMDREC_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 1
+                for q in alive:                      # a rank died: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+N_ADS = 1_000_000
+if __name__ == "__main__":
+    _ARGS = parse_args()
+    if _ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(_ARGS, sys.argv[1:]))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-N_ADS = 1_000_000
 DIM = 256
 USERS_PER_GPU = 512
 STAGE1_K = 500
@@ -158,36 +229,41 @@ def parity_check(ref, out, n_users):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-users", type=int, default=192)
-    ap.add_argument("--sweep", action="store_true", help="also print the end-to-end latency sweep by batch (stderr)")
-    ap.add_argument("--no-search-sweep", action="store_true",
-                    help="skip the search-only B sweep that fills the line's `search.sweep` (< 1 s)")
-    ap.add_argument("--corpus", choices=["random", "clustered"], default=None,
-                    help="synthetic corpus: randn unit rows (the reference benchmark's, default for flat) or a "
-                         "clustered one (default for ivf: an inverted file needs structure to exploit)")
-    ap.add_argument("--full-lists", action="store_true",
-                    help="N > 1: every shard sends its full top-500 (default: short lists with a proof of exactness)")
-    ap.add_argument("--ads", type=int, default=N_ADS, help="corpus size (configs[3]: 10000000)")
-    ap.add_argument("--index", choices=["flat", "ivf"], default="flat", help="configs[4]: ivf")
-    ap.add_argument("--nlist", type=int, default=4096, help="IVF lists of the coarse quantizer shared by all ranks (whole corpus)")
-    ap.add_argument("--nprobe", type=int, default=64, help="IVF probes per query (every rank scans its slice of each probed list)")
-    args = ap.parse_args()
+    args = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if world != args.gpus:
+        # never report a line whose n_gpus differs from what was asked for (a missing WORLD_SIZE with --gpus N > 1 is
+        # handled by launch_ranks before this point)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: refusing to run")
     # Rehearsal switch (not used by the driver): AMDREC_BENCH_REHEARSE=1 runs all ranks on cuda:0 over
     # gloo, so the N>1 code path can be exercised on a one-GPU box.  The numbers it prints are meaningless.
     rehearse = os.environ.get("AMDREC_BENCH_REHEARSE") == "1"
+    backend = "gloo" if (rehearse or args.dry_run) else "nccl"
+    if args.dry_run:
+        # launch-path check only: rendezvous + world-size agreement, no GPU (tests/test_bench_launch.py)
+        if os.environ.get("AMDREC_BENCH_FAIL_RANK") == str(rank):       # test hook: a rank that dies before the rendezvous
+            raise SystemExit(f"bench.py: rank {rank} failing on request (AMDREC_BENCH_FAIL_RANK)")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            seen = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(seen)
+            if int(seen.item()) != args.gpus or dist.get_world_size() != args.gpus:
+                raise SystemExit(f"bench.py: world formed with {int(seen.item())} ranks, --gpus {args.gpus}")
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (launch path only, nothing measured)", "value": None, "n_gpus": world,
+                              "dry_run": True, "config": {"backend": backend, "world": world}}), flush=True)
+        return
     if rehearse:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible "
+                         "(AMDREC_BENCH_REHEARSE=1 runs all ranks on cuda:0 over gloo to rehearse the code path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -196,6 +272,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from amdrec import _lib, synth
     from amdrec.index import FAISSIndex
@@ -234,9 +312,11 @@ def main():
     if world > 1:
         from amdrec.sharded import ShardedRecommender
         runner = ShardedRecommender(rec, rank, world, shard_offset=row0, shard_k=None if args.full_lists else "auto")
-        # short per-shard lists (amdrec.sharded): the proof of exactness is a device counter checked outside the timed
-        # region (after the warm-up and again after the timed steps; the batch is the same every step)
-        step = lambda: runner.recommend_device(uc, un, TOP_K, STAGE1_K, verify=False)     # noqa: E731
+        # The drop-in's DEFAULT mode (verify=True): with short per-shard lists every step checks the merge's proof of
+        # exactness (one 4-byte all-reduce + a host read) before it returns and repeats an unproven batch with full lists,
+        # all inside the timed region.  The unverified mode (the caller checks inexact_count() once per reporting
+        # interval) is timed separately below and reported as `no_verify`.
+        step = lambda: runner.recommend_device(uc, un, TOP_K, STAGE1_K)     # noqa: E731
     else:
         step = lambda: rec.recommend_device(uc, un, TOP_K, STAGE1_K)        # noqa: E731
 
@@ -247,12 +327,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    short_lists = None
-    if world > 1:
-        short_lists = {"list_k": runner.list_k(STAGE1_K), "k": STAGE1_K, "inexact_in_warmup": runner.inexact_count()}
-        if short_lists["inexact_in_warmup"]:                 # not provably exact on this corpus: full lists from here on
-            runner.shard_k = None
-            step()
     barrier()
     # Per-kernel table: HIP events around EVERY tagged launch, in a pre-pass outside the timed region.  An event pair
     # costs the stream ~10 us of idle GPU per launch (kernel trace: 0.2 us between untimed kernels, 5-10 us around timed
@@ -264,9 +338,9 @@ def main():
     torch.cuda.synchronize(device)
     prof_all = _lib.profile_report()
     dom_tag = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else ""
-    if world > 1:
-        runner.inexact_count()               # the pre-pass used the same batch: clear the counter
-    for attempt in range(2):
+    stats0 = runner.short_list_stats() if world > 1 else None
+
+    def timed_region(fn):
         barrier()
         _lib.profile_enable(True, only=dom_tag)  # HIP events around the dominant kernel's launches, on the launch stream
         # per-step HIP events on the launch stream (torch's current stream IS the stream every kernel is enqueued on,
@@ -275,31 +349,37 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             marks[i].record()
-            out = step()
+            res = fn()
         marks[args.steps].record()
         barrier()
-        dt = time.perf_counter() - t0
-        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-        prof = _lib.profile_report()
+        dt_ = time.perf_counter() - t0
+        ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        prof_ = _lib.profile_report()
         _lib.profile_enable(False)
-        if world == 1:
-            break
-        short_lists["list_k_timed"] = runner.list_k(STAGE1_K)
-        short_lists["inexact_in_timed_steps"] = runner.inexact_count()      # collective: the same value on every rank
-        if not short_lists["inexact_in_timed_steps"]:
-            break
-        # a timed step was not provably exact (cannot happen with the batch the warm-up already checked, but a wrong
-        # number must not be reported): time the region again with full lists
-        if attempt == 1:
-            raise SystemExit("timed steps not provably exact even with full shard lists")
-        runner.shard_k = None
-        short_lists["retimed_with_full_lists"] = True
-        step()
-        runner.inexact_count()
+        if world > 1:
+            tmax = torch.tensor([dt_], dtype=torch.float64, device="cpu" if rehearse else device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax.item())
+        return dt_, ms, prof_, res
+
+    dt, step_ms, prof, out = timed_region(step)
+    short_lists, no_verify, exchange = None, None, None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        st = runner.short_list_stats()
+        exchange = dict(runner.last_exchange)
+        short_lists = {"list_k": runner.list_k(STAGE1_K), "k": STAGE1_K, "list_k_timed": exchange["list_k"],
+                       "verified_every_step": True,
+                       "inexact_in_timed_steps": st["unproven_queries"] - stats0["unproven_queries"],
+                       "batches_repeated_with_full_lists_in_timed_steps": st["repeated_batches"] - stats0["repeated_batches"],
+                       "hit_rate": st["hit_rate"], "switched_off": st["switched_off"]}
+        if runner.list_k(STAGE1_K) < STAGE1_K:
+            # the same steps without the per-step check; a number is only reported if the proof held for every one of them
+            runner.inexact_count()
+            dt2, ms2, _, _ = timed_region(lambda: runner.recommend_device(uc, un, TOP_K, STAGE1_K, verify=False))
+            bad = runner.inexact_count()                     # collective: the same value on every rank
+            no_verify = {"value": round(B_global * args.steps / dt2, 1) if not bad else None,
+                         "ms_per_step": round(dt2 / args.steps * 1000, 3), "unproven_queries": bad,
+                         "note": "recommend_device(verify=False): the proof counter is read once after the region, not per step"}
     assert out["ad_ids"].shape[-1] == TOP_K
 
     if rank == 0:
@@ -379,7 +459,12 @@ def main():
                            "n_ads": n_ads, "dim": DIM, "users_per_step": B_global, "stage1_k": STAGE1_K,
                            "top_k": TOP_K, "corpus_rows_per_gpu": rows,
                            "parallelism": f"corpus row-sharded x{world}, ranker data-parallel over users",
-                           "shard_lists": short_lists},
+                           "backend": None if world == 1 else ("gloo" if rehearse else "nccl"),   # torch "nccl" == RCCL on ROCm
+                           "rehearsal_all_ranks_on_one_gpu": bool(rehearse and world > 1),
+                           "world": dist.get_world_size() if world > 1 else 1,
+                           "exchange": exchange["kind"] if exchange else None,
+                           "bytes_per_rank": exchange["bytes_per_rank"] if exchange else None,
+                           "shard_lists": short_lists, "no_verify": no_verify},
                 "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "kernels": kernels,
                 "kernels_note": (f"per-kernel table from {n_pre} steps with HIP events around every tagged launch, run before "
                                  "the timed region; the timed region records events around the dominant kernel only "

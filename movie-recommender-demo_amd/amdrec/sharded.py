@@ -17,9 +17,12 @@ rows [offset_r, offset_r + n_r); weights and the ad-feature table are replicated
 
 Short lists (``shard_k``): a randomly sharded corpus puts k/G +- sqrt(k/G) of a user's top-k rows on each shard, so a
 shard need not produce (re-score exactly, sort, send) its own top-k: it sends its best ``short_list_k(k, G)`` rows
-(128 instead of 500 at G = 8) and the merge PROVES the result exact - every shard's last sent score lies below the merged
-k-th score (``amdrec_topk_merge_partial``) - or counts the query as inexact, in which case the step is repeated with full
-lists and short lists are switched off for this recommender (a corpus sharded by topic defeats the premise).
+(128 instead of 500 at G = 8) and the merge PROVES the result exact - no shard's list ends strictly ahead of the merged
+k-th entry in the search's (score, position) order (``amdrec_topk_merge_partial``; a tie in score alone is not a failure:
+duplicate ads are routine) - or counts the query as inexact, in which case THAT batch is repeated with full lists.  Short
+lists are switched off for the recommender only when the failures are not occasional (``SHORT_LIST_MAX_FAIL_FRAC`` of a
+batch's queries, or ``SHORT_LIST_MAX_REPEAT_FRAC`` of the recent batches: a corpus sharded by topic defeats the premise);
+``short_list_stats()`` reports the hit rate.
 
 The compute steps go through an ``engine`` so that the orchestration (slicing, packing, the
 collective, offsets) can be exercised on CPU under gloo with a test engine; the default
@@ -104,18 +107,32 @@ def share_ivf_centroids(index, train_rows, rank: int, world: int, group=None, sr
     At query time all ranks compute identical probes (same centroids, same queries), scan their slices, and the usual
     top-k exchange + merge returns exactly the unsharded IVF result."""
     dev = index.device
+    err = None
     if rank == src:
-        index.train(train_rows)
-        cent = index.centroids.clone()
+        try:
+            index.train(train_rows)
+            cent = index.centroids.clone()
+        except Exception as e:                  # the peers are about to wait in a collective: tell them first
+            err = e
+            cent = torch.empty((index.nlist, index.dimension), dtype=torch.float32, device=dev)
     else:
         cent = torch.empty((index.nlist, index.dimension), dtype=torch.float32, device=dev)
     if world > 1:
-        if cent.is_cuda and dist.get_backend(group) == "gloo":
+        gloo = dist.get_backend(group) == "gloo"
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device="cpu" if gloo else dev)
+        dist.broadcast(ok, src=src, group=group)                    # status first: every rank raises together
+        if int(ok.item()) != 1:
+            if err is not None:
+                raise err
+            raise RuntimeError(f"share_ivf_centroids: training failed on rank {src}")
+        if cent.is_cuda and gloo:
             h = cent.cpu()
             dist.broadcast(h, src=src, group=group)
             cent.copy_(h)
         else:
             dist.broadcast(cent, src=src, group=group)
+    elif err is not None:
+        raise err
     if rank != src:
         index.set_trained_centroids(cent)
     return cent
@@ -142,6 +159,11 @@ def all_to_all_bytes(out: torch.Tensor, inp: torch.Tensor, group=None):
         dist.all_to_all_single(out, inp, group=group)
 
 
+SHORT_LIST_MAX_FAIL_FRAC = 0.05      # one batch with more than this share of unproven queries: the premise is false
+SHORT_LIST_MAX_REPEAT_FRAC = 0.25    # ... or more than this share of the last SHORT_LIST_WINDOW batches repeated
+SHORT_LIST_WINDOW = 16
+
+
 class ShardedRecommender:
     def __init__(self, rec, rank: int, world: int, shard_offset: int, group: Optional[dist.ProcessGroup] = None,
                  engine=None, exchange: str = "auto", shard_k="auto"):
@@ -158,6 +180,9 @@ class ShardedRecommender:
         self.shard_k = shard_k
         self.engine = engine if engine is not None else HipEngine(rec, shard_offset)
         self._inexact = None                 # device int32[1]: queries of THIS rank's users not proven exact, accumulated
+        self._recent = []                    # 1 per verified short-list batch that had to be repeated, else 0 (window)
+        self.stats = {"batches": 0, "queries": 0, "unproven_queries": 0, "repeated_batches": 0, "switched_off": False}
+        self.last_exchange = None            # {"kind", "bytes_per_rank", "list_k"} of the most recent step
 
     def list_k(self, stage1_k: int) -> int:
         if self.shard_k is None or self.world <= 1:
@@ -192,10 +217,31 @@ class ShardedRecommender:
         to the caller (``inexact_count()``, e.g. once per reporting interval)."""
         kq = self.list_k(stage1_k)
         out = self._step(user_categorical, user_numerical, top_k, stage1_k, kq)
-        if kq < stage1_k and verify and self.inexact_count() > 0:
-            self.shard_k = None                                               # this corpus is not randomly sharded
-            out = self._step(user_categorical, user_numerical, top_k, stage1_k, stage1_k)
+        if kq < stage1_k and verify:
+            bad = self.inexact_count()                                        # identical on every rank (all-reduce)
+            B = int(user_categorical.shape[0])
+            st = self.stats
+            st["batches"] += 1
+            st["queries"] += B
+            st["unproven_queries"] += bad
+            self._recent = (self._recent + [1 if bad else 0])[-SHORT_LIST_WINDOW:]
+            if bad:
+                # per-batch fallback: only this batch pays the second exchange; the decision to give short lists up for
+                # good needs more than an occasional unlucky query (every rank sees the same counts: same decision)
+                st["repeated_batches"] += 1
+                out = self._step(user_categorical, user_numerical, top_k, stage1_k, stage1_k)
+                often = len(self._recent) >= 4 and sum(self._recent) > SHORT_LIST_MAX_REPEAT_FRAC * len(self._recent)
+                if bad > SHORT_LIST_MAX_FAIL_FRAC * B or often:
+                    self.shard_k = None                                       # this corpus is not randomly sharded
+                    st["switched_off"] = True
         return out
+
+    def short_list_stats(self):
+        """Verified short-list batches so far: queries proven exact on the first exchange / all queries (hit rate),
+        batches repeated with full lists, and whether short lists were switched off."""
+        st = dict(self.stats)
+        st["hit_rate"] = 1.0 - st["unproven_queries"] / st["queries"] if st["queries"] else None
+        return st
 
     def _step(self, uc, un, top_k: int, k_out: int, k: int):
         """One exchange with lists of k entries per shard, merged to k_out candidates per user."""
@@ -218,6 +264,7 @@ class ShardedRecommender:
             sv[:, s_bytes:].view(torch.int32).copy_(pos.reshape(self.world, nq * k))    # int64 -> int32 on the wire
             recv = torch.empty_like(send)
             all_to_all_bytes(recv, send, self.group)                          # ONE collective per step
+            self.last_exchange = {"kind": "all_to_all", "bytes_per_rank": int(send.numel()), "list_k": k}
             cand_scores, cand_pos = self._merge(recv, nq, k, 0, nq, k_out, inexact)
         else:
             s_bytes, chunk = packed_layout(B, k)
@@ -226,6 +273,7 @@ class ShardedRecommender:
             buf[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))        # int64 -> int32 on the wire
             gathered = torch.empty(chunk * self.world, dtype=torch.uint8, device=scores.device)
             all_gather_bytes(gathered, buf, self.group)                       # ONE collective per step
+            self.last_exchange = {"kind": "all_gather", "bytes_per_rank": int(buf.numel()), "list_k": k}
             cand_scores, cand_pos = self._merge(gathered, B, k, q0, nq, k_out, inexact)
         out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
         out["candidate_scores"] = cand_scores

@@ -300,10 +300,14 @@ __global__ __launch_bounds__(512) void fixup_merge_kernel(const unsigned long lo
 
 // Cross-shard merge: n_lists sorted lists of list_k entries per query (one per corpus shard, positions
 // already global) -> the global top-k.  One block per query, bitonic sort in LDS.
-// Short lists (list_k < k, amdrec_topk_merge_partial): a shard sends only its best list_k rows; the merged top-k is the
-// exact global top-k iff no shard was cut off above the merged k-th score, i.e. every FULL list's last score is below
-// it (rows the shard did not send score no more than its last entry).  A query for which that cannot be shown - a full
-// list whose last score reaches the merged k-th, ties included, or fewer than k merged entries - is counted in *inexact.
+// Short lists (list_k < k, amdrec_topk_merge_partial): a shard sends only its best list_k rows in the search's own total
+// order (score descending, ties -> lower position), so every row it did NOT send is strictly behind its last entry in
+// that order.  The merged top-k is therefore the exact global top-k iff no FULL list's last entry lies strictly ahead of
+// the merged k-th entry - compared as (score, position) keys, the order the merge itself sorts by.  A tie in SCORE alone
+// proves nothing either way and is not counted (duplicate ads with bit-identical embeddings are routine,
+// training_pipeline.py:523): the last entry of a list may BE the merged k-th, or tie with it at a higher position, and
+// the rows behind it still cannot enter.  A query for which the rule fails - a full list that ends ahead of the merged
+// k-th key, or fewer than k merged entries - is counted in *inexact.
 __global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, const char* pos, int n_lists, int list_k,
                                                          long long list_stride_bytes, long long q0, int k,
                                                          float* outD, long long* outI, int* inexact) {
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, con
             const long long p = pg[(q0 + q) * list_k + list_k - 1];
             const float sc = sg[(q0 + q) * list_k + list_k - 1];
             const bool full = p >= 0 && sc == sc;
-            cut |= full && (kth == 0ull || sc >= key_score(kth));
+            cut |= full && (kth == 0ull || make_key(sc, (uint32_t)p) > kth);
         }
         if (__syncthreads_or(cut) && threadIdx.x == 0) atomicAdd(inexact, 1);
     }

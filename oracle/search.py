@@ -93,17 +93,23 @@ def merge_shards(Ds, Is, offsets, k):
 
 
 def merge_partial(Ds, Is, offsets, k):
-    """Merge of SHORT per-shard lists (each [nq, list_k], list_k <= k): -> (D, I, inexact[nq] bool).  The merged top-k
-    is proven exact when every FULL list's last score is strictly below the merged k-th score (rows a shard did not
-    send score at most its last entry); ties and a merged list shorter than k count as not proven."""
+    """Merge of SHORT per-shard lists (each [nq, list_k], list_k <= k): -> (D, I, inexact[nq] bool).  A shard's list is its
+    best list_k rows in the search's total order (score desc, lower position first), so a row it did not send is strictly
+    behind its last entry.  The merged top-k is proven exact when no FULL list's last entry lies strictly AHEAD of the
+    merged k-th entry in that order; a last entry that IS the merged k-th, or ties with its score at a higher position,
+    proves the list was cut at or below the boundary (score ties alone are not failures).  A merged list shorter than k
+    with a full shard list counts as not proven."""
     D, I = merge_shards(Ds, Is, offsets, k)
     nq = D.shape[0]
     inexact = np.zeros(nq, dtype=bool)
     for q in range(nq):
         have_k = I.shape[1] >= k and I[q, k - 1] >= 0
-        for d, i in zip(Ds, Is):
+        for d, i, off in zip(Ds, Is, offsets):
             full = i[q, -1] >= 0 and not np.isnan(d[q, -1])
-            if full and (not have_k or d[q, -1] >= D[q, k - 1]):
+            if not full:
+                continue
+            ahead = have_k and (d[q, -1] > D[q, k - 1] or (d[q, -1] == D[q, k - 1] and i[q, -1] + off < I[q, k - 1]))
+            if not have_k or ahead:
                 inexact[q] = True
     return D, I, inexact
 

@@ -72,25 +72,47 @@ def _inputs(B=B):
     return tt_sd, rk_sd, ad_table, corpus, uc, un
 
 
-def _worker(rank, world, port, q, B=B, exchange="auto", shard_k=None, sort_corpus=False):
+def _dup_corpus(corpus, ad_table):
+    """Every ad twice, the copy on the other shard of a 2-way split (bit-identical embeddings: score ties everywhere)."""
+    h = N_ADS // 2
+    return np.concatenate([corpus[:h], corpus[:h]]), np.concatenate([ad_table[:h], ad_table[:h]])
+
+
+class FlakyEngine(OracleEngine):
+    """Reports one unproven query in the first short-list merge on rank 0 (an unlucky 6-sigma query, injected)."""
+    calls = 0
+
+    def merge(self, gathered, world, n_users, k, q0, nq, k_out=None, inexact=None):
+        out = super().merge(gathered, world, n_users, k, q0, nq, k_out, inexact)
+        if inexact is not None and self.offset == 0 and self.calls == 0:
+            inexact += 1
+        self.calls += 1
+        return out
+
+
+def _worker(rank, world, port, q, B=B, exchange="auto", shard_k=None, sort_corpus=False, dup=False, flaky=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(B)
-        per = (N_ADS + world - 1) // world
-        lo, hi = rank * per, min(N_ADS, (rank + 1) * per)
+        if dup:
+            corpus, ad_table = _dup_corpus(corpus, ad_table)
+        n_ads = len(corpus)
+        per = (n_ads + world - 1) // world
+        lo, hi = rank * per, min(n_ads, (rank + 1) * per)
         if sort_corpus:          # shard 0 holds user 0's best rows: the premise of short lists (random sharding) is false
             emb = oracle.search.normalize_l2(oracle.towers.user_tower(tt_sd, uc, un))
             order = np.argsort(-(oracle.search.normalize_l2(corpus) @ emb[0]), kind="stable")
             corpus, ad_table = corpus[order], ad_table[order]
-        eng = OracleEngine(tt_sd, rk_sd, corpus[lo:hi], lo, ad_table)
+        eng = (FlakyEngine if flaky else OracleEngine)(tt_sd, rk_sd, corpus[lo:hi], lo, ad_table)
         sr = ShardedRecommender(None, rank, world, lo, engine=eng, exchange=exchange, shard_k=shard_k)
         used_k = sr.list_k(K1)
         out = sr.recommend_device(torch.from_numpy(uc), torch.from_numpy(un), TOPK, K1)
         q.put((rank, out["user_offset"], out["ad_ids"].numpy(), out["scores"].numpy(),
-               out["candidate_ids"].numpy(), out["candidate_scores"].numpy(), used_k, sr.shard_k))
+               out["candidate_ids"].numpy(), out["candidate_scores"].numpy(), used_k, sr.shard_k, sr.short_list_stats(),
+               sr.last_exchange))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -125,7 +147,7 @@ def test_two_rank_sharded_pipeline_equals_unsharded_oracle(B, exchange):
     oidx.add(corpus)
     ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
     covered = []
-    for rank, q0, ids, sc, cand, cs, _, _ in res:
+    for rank, q0, ids, sc, cand, cs, *_ in res:
         assert (q0, len(ids)) == user_slice(B, rank, world)
         for j in range(len(ids)):
             r = ref[q0 + j]
@@ -144,8 +166,8 @@ def test_two_rank_sharded_pipeline_equals_unsharded_oracle(B, exchange):
 def test_short_shard_lists_are_proven_exact_or_repeated(shard_k, sort_corpus, exchange):
     """Short lists (amdrec.sharded, amdrec_topk_merge_partial): 40 of 50 entries per shard on a randomly ordered corpus
     -> proven exact, no repeat; 26 entries on a corpus sorted by user 0's score (all of user 0's best rows on shard 0)
-    -> the proof fails, the step is repeated with full lists and short lists are switched off.  Either way the result
-    is the unsharded oracle's, bit for bit."""
+    -> the proof fails for 1 of 8 queries (> SHORT_LIST_MAX_FAIL_FRAC), the step is repeated with full lists and short
+    lists are switched off.  Either way the result is the unsharded oracle's, bit for bit."""
     world, Bn = 2, 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -165,9 +187,11 @@ def test_short_shard_lists_are_proven_exact_or_repeated(shard_k, sort_corpus, ex
     oidx = oracle.search.FlatIndex(256)
     oidx.add(corpus)
     ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
-    for rank, q0, ids, sc, cand, cs, used_k, shard_k_after in res:
+    for rank, q0, ids, sc, cand, cs, used_k, shard_k_after, stats, _ in res:
         assert used_k == shard_k
         assert shard_k_after == (None if sort_corpus else shard_k)
+        assert stats["batches"] == 1 and stats["repeated_batches"] == int(sort_corpus)
+        assert stats["switched_off"] == sort_corpus and (stats["hit_rate"] == 1.0) == (not sort_corpus)
         for j in range(len(ids)):
             r = ref[q0 + j]
             assert np.array_equal(cand[j], r["candidate_ids"])
@@ -195,7 +219,7 @@ def test_four_rank_short_lists_all_to_all():
     oidx.add(corpus)
     ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
     covered = []
-    for rank, q0, ids, sc, cand, cs, used_k, shard_k_after in res:
+    for rank, q0, ids, sc, cand, cs, used_k, shard_k_after, stats, _ in res:
         assert (q0, len(ids)) == user_slice(Bn, rank, world) and used_k == 24 and shard_k_after in (24, None)
         for j in range(len(ids)):
             r = ref[q0 + j]
@@ -216,13 +240,26 @@ def test_short_list_length_and_merge_rule():
     D, I, bad = oracle.search.merge_partial([D0, D1], [I0, I1], [0, 0], 3)
     assert I.tolist() == [[0, 1, 5]] and bad.tolist() == [True]        # shard 0's last (8) >= merged 3rd (7): not proven
     D, I, bad = oracle.search.merge_partial([D0, D1], [I0, I1], [0, 0], 2)
-    assert I.tolist() == [[0, 1]] and bad.tolist() == [True]           # tie with the cut-off entry counts as not proven
+    assert I.tolist() == [[0, 1]] and bad.tolist() == [False]          # shard 0's last entry IS the merged 2nd: what it
+    #                                                                    did not send is strictly behind it -> proven
     D0b = np.array([[9., 6.]], dtype=np.float32)
     D, I, bad = oracle.search.merge_partial([D0b, D1], [I0, I1], [0, 0], 2)
     assert I.tolist() == [[0, 5]] and bad.tolist() == [False]          # both lasts (6, 1) below the merged 2nd (7)
     D1s, I1s = np.array([[7., -np.inf]], dtype=np.float32), np.array([[5, -1]])   # a shard with one row: not full
     D, I, bad = oracle.search.merge_partial([D0b, D1s], [I0, I1s], [0, 0], 3)
-    assert I.tolist() == [[0, 5, 1]] and bad.tolist() == [True]        # shard 0 full and its last (6) IS the merged 3rd
+    assert I.tolist() == [[0, 5, 1]] and bad.tolist() == [False]       # shard 0 full, its last (6) IS the merged 3rd
+    # score ties at the boundary are decided by position, like the merge itself: a last entry that ties with the merged
+    # k-th at a HIGHER position is behind it (proven); at a LOWER position it is ahead (the shard may hold more such rows)
+    Dt0, It0 = np.array([[9., 7.]], dtype=np.float32), np.array([[0, 9]])
+    Dt1, It1 = np.array([[7., 7.]], dtype=np.float32), np.array([[5, 6]])
+    D, I, bad = oracle.search.merge_partial([Dt0, Dt1], [It0, It1], [0, 0], 3)
+    assert I.tolist() == [[0, 5, 6]] and bad.tolist() == [False]       # lasts: (7, pos 9) behind, (7, pos 6) IS the 3rd
+    D, I, bad = oracle.search.merge_partial([Dt0, Dt1], [It0, It1], [0, 0], 2)
+    assert I.tolist() == [[0, 5]] and bad.tolist() == [False]          # both lasts tie with (7, pos 5) from behind
+    Du0, Iu0 = np.array([[9., 7.]], dtype=np.float32), np.array([[0, 3]])
+    D, I, bad = oracle.search.merge_partial([Du0, Dt1], [Iu0, It1], [0, 0], 3)
+    assert I.tolist() == [[0, 3, 5]] and bad.tolist() == [True]        # shard 0 ends at (7, pos 3), AHEAD of the merged
+    #                                                                    3rd (7, pos 5): it may hold an unsent (7, pos 4)
 
 
 def test_user_slice_and_layout():
@@ -310,3 +347,110 @@ def test_two_rank_sharded_ivf_with_shared_centroids_equals_unsharded_ivf():
         for j in range(len(cand)):
             # union of the ranks' slices of the probed lists == the unsharded lists: bit-identical result
             assert np.array_equal(cand[j], rI[q0 + j]) and np.array_equal(cs[j], rD[q0 + j])
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("shard_k,repeats", [(26, 0), (25, 1)])
+def test_short_lists_on_a_corpus_of_duplicated_ads(shard_k, repeats):
+    """real catalogs hold ads with bit-identical embeddings (the AdTower embeds categorical features only,
+    training_pipeline.py:523), so score ties at the k-th place are routine.  Corpus = every ad twice, the copy on the other
+    shard: the merged top-50 is 25 pairs and the 50th entry ties with the 49th.  26-entry lists end below the boundary ->
+    proven, no repeat, although the k-th score is tied; 25-entry lists: shard 1's last entry IS the merged 50th (fine),
+    shard 0's last is its twin at the lower position, i.e. ahead of it -> not provable (shard 0 might hold a third copy)
+    -> THAT batch is repeated with full lists.  Bit-equal to the unsharded oracle either way."""
+    world, Bn = 2, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, Bn, "auto", shard_k, False, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(Bn)
+    corpus, ad_table = _dup_corpus(corpus, ad_table)
+    oidx = oracle.search.FlatIndex(256)
+    oidx.add(corpus)
+    ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
+    h = N_ADS // 2
+    for rank, q0, ids, sc, cand, cs, used_k, shard_k_after, stats, exch in res:
+        assert used_k == shard_k and stats["batches"] == 1 and stats["repeated_batches"] == repeats
+        assert exch["kind"] == "all_to_all" and exch["list_k"] == (K1 if repeats else shard_k)
+        assert exch["bytes_per_rank"] == Bn * exch["list_k"] * 8
+        for j in range(len(ids)):
+            r = ref[q0 + j]
+            assert np.array_equal(cand[j], r["candidate_ids"]) and np.array_equal(cs[j], r["candidate_scores"])
+            assert ids[j].tolist() == r["ad_ids"]
+            assert np.array_equal(cand[j][0::2] + h, cand[j][1::2])          # pairs: an ad and its twin on the other shard
+            assert cs[j][K1 - 1] == cs[j][K1 - 2]                            # the k-th score IS tied
+
+
+@pytest.mark.timeout(300)
+def test_an_occasional_unproven_query_repeats_its_batch_but_keeps_short_lists():
+    """1 unproven query of 32 (3 % < SHORT_LIST_MAX_FAIL_FRAC): the batch is repeated with full lists, the recommender
+    keeps its short lists (a tie / an unlucky query must not be a permanent switch)."""
+    world, Bn = 2, 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, Bn, "auto", 40, False, False, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=280) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(Bn)
+    oidx = oracle.search.FlatIndex(256)
+    oidx.add(corpus)
+    ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, TOPK, K1)
+    for rank, q0, ids, sc, cand, cs, used_k, shard_k_after, stats, exch in res:
+        assert stats["repeated_batches"] == 1 and stats["unproven_queries"] == 1 and not stats["switched_off"]
+        assert shard_k_after == 40 and abs(stats["hit_rate"] - (1 - 1 / 32)) < 1e-9
+        assert exch["list_k"] == K1                                           # the repeat ran with full lists
+        for j in range(len(ids)):
+            r = ref[q0 + j]
+            assert np.array_equal(cand[j], r["candidate_ids"]) and ids[j].tolist() == r["ad_ids"]
+
+
+def _centroid_fail_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from amdrec.sharded import share_ivf_centroids
+
+        class Idx:
+            device, nlist, dimension = torch.device("cpu"), 8, 4
+
+            def train(self, rows):
+                raise ValueError("Number of training points (3) should be at least as large as number of clusters (8)")
+
+            def set_trained_centroids(self, c):
+                raise AssertionError("must not be reached")
+        try:
+            share_ivf_centroids(Idx(), torch.zeros(3, 4), rank, world)
+            q.put((rank, "returned"))
+        except Exception as e:                                       # noqa: BLE001
+            q.put((rank, type(e).__name__))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_failed_centroid_training_raises_on_every_rank_instead_of_hanging():
+    """only rank 0 trains; if that raises, the peers (already waiting in the broadcast) must raise too."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_centroid_fail_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res == {0: "ValueError", 1: "RuntimeError"}

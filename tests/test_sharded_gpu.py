@@ -106,6 +106,65 @@ def test_short_list_merge_is_proven_exact_or_flagged(list_k, clustered):
     assert np.array_equal(pos2.cpu().numpy(), oI[3:12]) and int(inexact.item()) == int(bad.sum()) + int(bad[3:12].sum())
 
 
+@pytest.mark.parametrize("list_k", [250, 251, 320])
+def test_short_list_merge_on_duplicated_ads_decides_score_ties_by_position(list_k):
+    """a corpus of duplicated ads (every row twice, the copy on the other shard) makes the merged k-th score a
+    tie for every query.  amdrec_topk_merge_partial must decide like the merge itself, by (score, position): 251+ entries
+    per shard end below the boundary -> proven although the k-th score is tied; 250 entries: shard 1's last entry IS the
+    merged 500th (fine), shard 0's last is its twin at the lower position = ahead of it -> counted for every query.
+    Result and count equal oracle.search.merge_partial; a proven result equals the unsharded HIP search bit for bit."""
+    from amdrec.index import FAISSIndex
+    from amdrec.sharded import HipEngine, packed_layout
+    h, nq, k, G = 30_000, 12, 500, 2
+    half = synth.unit_corpus(h, 256, seed=21)
+    xb, xq = np.concatenate([half, half]), synth.unit_corpus(nq, 256, seed=22)
+    full = FAISSIndex(256, index_type="Flat")
+    full.add(xb)
+    q = torch.from_numpy(xq).cuda()
+    ref_pos, ref_sc = full.search_device(q, k, return_positions=True)
+    assert torch.equal(ref_pos[:, 0::2] + h, ref_pos[:, 1::2]) and torch.equal(ref_sc[:, k - 1], ref_sc[:, k - 2])
+    s_bytes, chunk = packed_layout(nq, list_k)
+    gathered = torch.empty(chunk * G, dtype=torch.uint8, device="cuda")
+    Ds, Is = [], []
+    for g in range(G):
+        sh = FAISSIndex(256, index_type="Flat")
+        sh.add(xb[g * h:(g + 1) * h])
+        pos, sc = sh.search_device(q, list_k, return_positions=True, pos_offset=g * h)
+        c = gathered[g * chunk:(g + 1) * chunk]
+        c[:nq * list_k * 4].view(torch.float32).copy_(sc.reshape(-1))
+        c[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))
+        Ds.append(sc.cpu().numpy())
+        Is.append(pos.cpu().numpy())
+    oD, oI, bad = oracle.search.merge_partial(Ds, Is, [0] * G, k)
+    inexact = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sc, pos = HipEngine(None, 0).merge(gathered, G, nq, list_k, 0, nq, k, inexact)
+    assert np.array_equal(pos.cpu().numpy(), oI) and np.array_equal(sc.cpu().numpy(), oD)
+    assert int(inexact.item()) == int(bad.sum()) == (nq if list_k == 250 else 0)
+    assert torch.equal(pos, ref_pos) and torch.equal(sc, ref_sc)      # (here even the unproven merge happens to be right)
+
+
+def test_bench_rehearsal_two_ranks_on_one_gpu_prints_n_gpus_2():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts its two ranks itself; under the rehearsal
+    switch both run on cuda:0 over gloo.  One JSON line, n_gpus 2, the exchange described in config."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["AMDREC_BENCH_REHEARSE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--ads", "200000"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["scaling"] == "weak" and doc["value"] > 0
+    cfg = doc["config"]
+    assert cfg["world"] == 2 and cfg["backend"] == "gloo" and cfg["exchange"] == "all_to_all"
+    assert cfg["bytes_per_rank"] == 1024 * cfg["shard_lists"]["list_k_timed"] * 8
+    assert cfg["users_per_step"] == 1024 and cfg["shard_lists"]["inexact_in_timed_steps"] == 0
+
+
 def test_sharded_recommender_single_rank_rccl_matches_pipeline():
     import torch.distributed as dist
     from amdrec.sharded import ShardedRecommender
