@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -87,7 +88,17 @@ def load():
     return lib
 
 
+_tls = threading.local()          # .prev_device: the thread's HIP device before stream_ptr() switched it (else None)
+
+
 def check(status):
+    """Status check of a C call - and the end of the call's device scope: if ``stream_ptr`` switched the calling
+    thread's current HIP device for this call, switch it back (a call on a tensor that lives on cuda:N must not leave
+    the caller's later ``device='cuda'`` allocations and launches on cuda:N)."""
+    prev = getattr(_tls, "prev_device", None)
+    if prev is not None:
+        _tls.prev_device = None
+        torch.cuda.set_device(prev)
     if status != 0:
         msg = load().amdrec_last_error()
         raise AmdrecError(f"libamdrec error {status}: {msg.decode() if msg else '?'}")
@@ -100,12 +111,17 @@ def ptr(t):
 
 def stream_ptr(device=None):
     """hipStream_t of torch's current stream on ``device`` - and make ``device`` the calling thread's current HIP
-    device: the C entry points launch kernels, set function attributes and memset on the CURRENT device (amdrec.h),
-    so a tensor on cuda:N (N != 0), or a call from a fresh thread (whose current device is 0), must switch first.
-    Every binding call site evaluates this right before the C call."""
+    device for the duration of ONE C call: the C entry points launch kernels, set function attributes and memset on the
+    CURRENT device (amdrec.h), so a tensor on cuda:N (N != 0), or a call from a fresh thread (whose current device is
+    0), must switch first.  Every binding call site evaluates this as the last argument of ``check(lib.fn(...,
+    stream_ptr(dev)))``: the switch happens right before the C call and ``check`` restores the previous device right
+    after it, so the caller's current device is unchanged by an amdrec call."""
     if device is not None:
         dev = torch.device(device)
-        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+        cur = torch.cuda.current_device()
+        if dev.type == "cuda" and dev.index is not None and dev.index != cur:
+            if getattr(_tls, "prev_device", None) is None:
+                _tls.prev_device = cur
             torch.cuda.set_device(dev)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 

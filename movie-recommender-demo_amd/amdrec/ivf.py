@@ -35,6 +35,7 @@ GROUPED_MIN_QUERIES = 16       # batches at least this large scan list-major (ev
 QTILE = 64                     # queries per grouped-scan tile (ShapeIvf::BP) ...
 QTILE_SPARSE = 32              # ... or 32 (ShapeIvf32) when fewer than SPARSE_PAIRS_PER_LIST queries probe a list on average
 SPARSE_PAIRS_PER_LIST = 24
+MAX_QUERY_TILES = 65535        # grid limit of one amdrec_ivf_scan_grouped launch (pairs / tile + nlist query tiles)
 TWO_PHASE_MIN_PROBES = 16      # from here on the scan is split: nearest probes unfiltered, the rest filtered by their k-th score
 
 
@@ -55,6 +56,17 @@ def _assign(x: torch.Tensor, cent: torch.Tensor) -> torch.Tensor:
                                      cent.stride(0), _lib.ptr(out), None, _lib.ptr(ws), ws.numel(),
                                      _lib.stream_ptr(x.device)))
     return out
+
+
+def grouped_chunk_limit(nlist: int, nprobe: int) -> int:
+    """Largest query chunk whose grouped scan fits one launch: a launch walks at most pairs / tile + nlist query tiles
+    (every list can end in a partial tile) and the tile is re-picked per (chunk, probe-column range) - a phase or a tail
+    chunk may fall under the sparse threshold - so the limit is taken with the SMALLEST tile.  A quantizer with more
+    lists than the grid has tiles cannot take the grouped path at all."""
+    room = MAX_QUERY_TILES - nlist
+    if room < 1:
+        raise ValueError(f"nlist = {nlist} is beyond the grouped IVF scan's limit ({MAX_QUERY_TILES - 1} lists)")
+    return max(1, (room * min(QTILE, QTILE_SPARSE)) // max(1, nprobe))
 
 
 class IVFState:
@@ -132,8 +144,8 @@ class IVFState:
         chunk = max(1, min(nq, 65535, POOL_BYTES // (pool_ld * 8)))
         grouped = nq >= GROUPED_MIN_QUERIES
         qtile = QTILE_SPARSE if min(chunk, nq) * nprobe < SPARSE_PAIRS_PER_LIST * self.nlist else QTILE
-        if grouped:                                   # one launch needs pairs/qtile + nlist <= 65535 query tiles
-            chunk = max(1, min(chunk, ((65535 - self.nlist) * qtile) // nprobe))
+        if grouped:
+            chunk = min(chunk, grouped_chunk_limit(self.nlist, nprobe))
         # one workspace: [candidate pool | grouping scratch | pair arrays and offsets]
         pool_bytes = (chunk * pool_ld * 8 + 255) // 256 * 256
         grp_bytes = ((self.nlist + 1) * 4 + 255) // 256 * 256 + (chunk * nprobe * 4 + 255) // 256 * 256
@@ -145,7 +157,7 @@ class IVFState:
         pair_q, pair_p = arr[:chunk * nprobe], arr[chunk * nprobe:2 * chunk * nprobe]
         goff = arr[2 * chunk * nprobe:2 * chunk * nprobe + self.nlist + 1]
         qtp = arr[2 * chunk * nprobe + self.nlist + 1:]
-        st = _lib.stream_ptr(self.device)
+        st = lambda: _lib.stream_ptr(self.device)      # noqa: E731  (per call: check() ends the call's device scope)
 
         def group_and_scan(s, m, col0, ncol, tau=None, fill=None, n_out=None):
             """(query, probe) pairs of probe columns [col0, col0 + ncol) grouped by list, then the grouped scan of those
@@ -154,12 +166,12 @@ class IVFState:
             pv = probes[s:, col0:]
             _lib.check(lib.amdrec_ivf_group(_lib.ptr(pv), nprobe, m, ncol, self.nlist, _lib.ptr(lens), _lib.ptr(base[s:]),
                                             _lib.ptr(n_out), _lib.ptr(pair_q), _lib.ptr(pair_p), _lib.ptr(goff),
-                                            _lib.ptr(qtp), qt, _lib.ptr(grp), grp.numel(), st))
+                                            _lib.ptr(qtp), qt, _lib.ptr(grp), grp.numel(), st()))
             _lib.check(lib.amdrec_ivf_scan_grouped(
                 _lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off), self.nlist, max_len,
                 _lib.ptr(q[s:]), q.stride(0), _lib.ptr(goff), _lib.ptr(qtp), (m * ncol) // qt + self.nlist, qt,
                 _lib.ptr(pair_q), _lib.ptr(pair_p), _lib.ptr(base[s:]), ncol, _lib.ptr(ws), pool_ld, pos_offset,
-                _lib.ptr(tau), 0 if tau is None else tau.stride(0), _lib.ptr(fill), st))
+                _lib.ptr(tau), 0 if tau is None else tau.stride(0), _lib.ptr(fill), st()))
 
         # Exact two-phase scan (batches that take the grouped scan, >= TWO_PHASE_MIN_PROBES probes): the nearest eighth of
         # the probes unfiltered -> select -> tau = that subset's k-th score, a LOWER bound of the final k-th score -> the other
@@ -173,19 +185,19 @@ class IVFState:
             if two_phase:
                 group_and_scan(s, m, 0, n_first, n_out=n_pool[s:])
                 _lib.check(lib.amdrec_ivf_select(_lib.ptr(ws), pool_ld, _lib.ptr(n_pool[s:]), m, k,
-                                                 _lib.ptr(out_scores[s:]), _lib.ptr(out_pos[s:]), st))
+                                                 _lib.ptr(out_scores[s:]), _lib.ptr(out_pos[s:]), st()))
                 group_and_scan(s, m, n_first, nprobe - n_first, tau=out_scores[s:, k - 1], fill=n_pool[s:], n_out=scratch_n)
             elif grouped:
                 group_and_scan(s, m, 0, nprobe, n_out=n_pool[s:])
             else:
                 _lib.check(lib.amdrec_ivf_group(_lib.ptr(probes[s:]), nprobe, m, nprobe, self.nlist, _lib.ptr(lens),
                                                 _lib.ptr(base[s:]), _lib.ptr(n_pool[s:]), _lib.ptr(pair_q), _lib.ptr(pair_p),
-                                                _lib.ptr(goff), _lib.ptr(qtp), qtile, _lib.ptr(grp), grp.numel(), st))
+                                                _lib.ptr(goff), _lib.ptr(qtp), qtile, _lib.ptr(grp), grp.numel(), st()))
                 _lib.check(lib.amdrec_ivf_scan(_lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off),
                                                _lib.ptr(q[s:]), m, q.stride(0), _lib.ptr(probes[s:]),
-                                               _lib.ptr(base[s:]), nprobe, _lib.ptr(ws), pool_ld, pos_offset, st))
+                                               _lib.ptr(base[s:]), nprobe, _lib.ptr(ws), pool_ld, pos_offset, st()))
             _lib.check(lib.amdrec_ivf_select(_lib.ptr(ws), pool_ld, _lib.ptr(n_pool[s:]), m, k,
-                                             _lib.ptr(out_scores[s:]), _lib.ptr(out_pos[s:]), st))
+                                             _lib.ptr(out_scores[s:]), _lib.ptr(out_pos[s:]), st()))
 
     # -- persistence ----------------------------------------------------------------------
     def export_arrays(self):

@@ -142,3 +142,44 @@ def test_index_id_codec_round_trips_types():
     for bad in ((1, 2), b"x", True, object()):
         with pytest.raises(TypeError):
             index._encode_id(bad)
+
+
+def test_grouped_ivf_chunk_limit_holds_for_every_tile_the_scan_may_pick():
+    """the query chunk of the grouped IVF scan was sized with the whole batch's tile; a phase / tail chunk
+    that falls under the sparse threshold re-picks the smaller tile and overran the launch's query-tile limit for
+    nlist above ~37k.  The limit now assumes the smallest tile."""
+    from amdrec import ivf
+    for nlist in (100, 4096, 37_000, 50_000, 65_000, 65_534):
+        for nprobe in (1, 10, 64, 256):
+            m = ivf.grouped_chunk_limit(nlist, nprobe)
+            assert m >= 1
+            for qt in (ivf.QTILE, ivf.QTILE_SPARSE):
+                for ncol in {1, max(1, nprobe // 8), nprobe - max(1, nprobe // 8) or 1, nprobe}:
+                    assert (m * ncol) // qt + nlist <= ivf.MAX_QUERY_TILES or m == 1
+    with pytest.raises(ValueError):
+        ivf.grouped_chunk_limit(65_535, 8)
+
+
+def test_stream_ptr_device_scope_is_restored_by_check(monkeypatch):
+    """a call on a tensor that lives on another device must not change the caller's current device.  The
+    binding switches in stream_ptr() (last argument of the C call) and switches back in check() (right after it)."""
+    import torch
+    from amdrec import _lib
+    state = {"cur": 0, "log": []}
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: state["cur"])
+
+    def set_device(d):
+        state["cur"] = torch.device(d).index if not isinstance(d, int) else d
+        state["log"].append(state["cur"])
+    monkeypatch.setattr(torch.cuda, "set_device", set_device)
+
+    class S:
+        cuda_stream = 1234
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: S())
+    p = _lib.stream_ptr(torch.device("cuda", 3))
+    assert p.value == 1234 and state["cur"] == 3
+    _lib.check(0)
+    assert state["cur"] == 0 and state["log"] == [3, 0]
+    _lib.stream_ptr(torch.device("cuda", 0))                 # already current: no switch, nothing to restore
+    _lib.check(0)
+    assert state["log"] == [3, 0]
