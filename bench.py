@@ -39,7 +39,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=192)
-    ap.add_argument("--sweep", action="store_true", help="also print the end-to-end latency sweep by batch (stderr)")
+    ap.add_argument("--sweep", action="store_true", help="(kept for old command lines: the latency sweep is in the line by default)")
     ap.add_argument("--no-search-sweep", action="store_true",
                     help="skip the search-only B sweep that fills the line's `search.sweep` (< 1 s)")
     ap.add_argument("--corpus", choices=["random", "clustered"], default=None,
@@ -51,6 +51,10 @@ def parse_args(argv=None):
     ap.add_argument("--index", choices=["flat", "ivf"], default="flat", help="configs[4]: ivf")
     ap.add_argument("--nlist", type=int, default=4096, help="IVF lists of the coarse quantizer shared by all ranks (whole corpus)")
     ap.add_argument("--nprobe", type=int, default=64, help="IVF probes per query (every rank scans its slice of each probed list)")
+    ap.add_argument("--no-strict-fp32", action="store_true",
+                    help="skip the second figure (`strict_fp32`: 5 steps with the ranker on the fp32-MFMA engine)")
+    ap.add_argument("--no-latency-sweep", action="store_true",
+                    help="skip `e2e_latency_by_batch` (one recommend_device call at B = 1 / 8 / 64 / 512, N = 1 only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="form the world (launcher, rendezvous, world-size checks), print a stub line with n_gpus and "
                          "exit without touching a GPU: the CPU test of the N > 1 launch path")
@@ -166,19 +170,7 @@ def pmc_traffic(tag, run_tags=()):
             "source": os.path.basename(files[-1])}
 
 
-def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, uc, un, n_users, user_chunk=32):
-    """The CPU oracle (port of the reference path) timed on this host's cores on a bounded sample of the same
-    workload: the FIRST n_users users of the GPU step's own batch against the full corpus, so that its output doubles
-    as a full-size parity check of the GPU step (parity_check).  The ranker leg is fed user_chunk users x 500
-    candidate rows per forward (the reference loops 500-row forwards, inference.py:310-317: the 8-core survey probe
-    of that form gave 38 recs/s)."""
-    import oracle
-    idx = oracle.search.FlatIndex(DIM)
-    idx.add(corpus_cpu)                                   # index build is not timed (nor is it on the GPU)
-    t0 = time.time()
-    ref = oracle.pipeline.recommend(tt_sd, rk_sd, idx, ad_table_cpu, uc[:n_users], un[:n_users], TOP_K, STAGE1_K,
-                                    user_chunk=user_chunk)
-    dt = time.time() - t0
+def _host_threads():
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
@@ -188,10 +180,101 @@ def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, uc, un, n_users, 
         threads = min(threads, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    return {"value": round(n_users / dt, 2), "unit": "recs/s", "cores": int(threads), "kind": "port",
-            "sample": f"the first {n_users} users of the timed batch x {len(corpus_cpu)} ads end-to-end through oracle/ "
-                      f"(numpy fp32 BLAS, {threads} threads, ranker fed {user_chunk} users x {STAGE1_K} rows per forward), "
-                      f"{dt:.1f}s; faiss unavailable - numpy restatement of IndexFlatIP"}, ref
+    return int(threads)
+
+
+def torch_cpu_pipeline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, uc, un, n_users, user_chunk=32, corpus_chunk=1 << 16):
+    """SURVEY.md section 8(d)'s CPU baseline when faiss is absent: the reference's pipeline restated on PyTorch-CPU -
+    the drop-in modules' ATen forwards (`autograd_forward`: the reference's own op sequence, two_tower_model.py:33-121,
+    transformer_ranker.py:310-380, literal 8-head attention) in eval mode under no_grad for the towers and the ranker,
+    IndexFlatIP restated as chunked `Q @ X^T` + `torch.topk` with a running merge (faiss_retrieval.py:146-155), the ranker
+    fed user_chunk users x 500 candidate rows per forward (inference.py:241-255 builds 500-row batches; rows are
+    independent), top-10 by CTR (inference.py:258-263).  -> (seconds, ad ids [n_users, TOP_K])."""
+    from amdrec.ranker import TransformerRanker
+    from amdrec.towers import TwoTowerModel
+    user, ad, nnum = dims
+    tt = TwoTowerModel(dict(user), dict(ad), nnum)
+    tt.load_state_dict(_t(tt_sd))
+    rk = TransformerRanker(dict(user), dict(ad), nnum)
+    rk.load_state_dict(_t(rk_sd))
+    tt.eval()
+    rk.eval()
+    X = torch.from_numpy(corpus_cpu)
+    table = torch.from_numpy(ad_table_cpu)
+    ucat, unum = torch.from_numpy(uc[:n_users]), torch.from_numpy(un[:n_users])
+    t0 = time.time()
+    with torch.no_grad():
+        q = tt.user_tower.autograd_forward(ucat, unum)
+        q = torch.nn.functional.normalize(q, p=2, dim=1)                  # faiss.normalize_L2 on the query copy (:146-147)
+        best_s = torch.empty((n_users, 0))
+        best_i = torch.empty((n_users, 0), dtype=torch.int64)
+        for s in range(0, X.shape[0], corpus_chunk):                       # IndexFlatIP.search (:155)
+            sc = q @ X[s:s + corpus_chunk].T
+            v, i = torch.topk(sc, min(STAGE1_K, sc.shape[1]), dim=1)
+            best_s, best_i = torch.cat([best_s, v], 1), torch.cat([best_i, i + s], 1)
+            if best_s.shape[1] > 4 * STAGE1_K:
+                v, j = torch.topk(best_s, STAGE1_K, dim=1)
+                best_s, best_i = v, torch.gather(best_i, 1, j)
+        v, j = torch.topk(best_s, STAGE1_K, dim=1)
+        cand = torch.gather(best_i, 1, j)
+        ids = torch.empty((n_users, TOP_K), dtype=torch.int64)
+        for b0 in range(0, n_users, user_chunk):
+            b1 = min(n_users, b0 + user_chunk)
+            rows = cand[b0:b1].reshape(-1)
+            pred = rk.autograd_forward(ucat[b0:b1].repeat_interleave(STAGE1_K, 0), table[rows],
+                                       unum[b0:b1].repeat_interleave(STAGE1_K, 0))
+            ctr = torch.sigmoid(pred["ctr"]).view(b1 - b0, STAGE1_K)
+            _ = torch.sigmoid(pred["engagement"]), torch.sigmoid(pred["revenue"])
+            top = torch.topk(ctr, TOP_K, dim=1).indices
+            ids[b0:b1] = torch.gather(cand[b0:b1], 1, top)
+    return time.time() - t0, ids.numpy()
+
+
+def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, uc, un, n_users, user_chunk=32, torch_leg=True):
+    """The reference's CPU path timed on this host's cores on a bounded sample of the same workload: the FIRST n_users
+    users of the GPU step's own batch against the full corpus, twice:
+      * the PyTorch-CPU restatement (torch_cpu_pipeline) - the reported baseline ("faiss unavailable
+        - torch-CPU restatement"; `import faiss` is attempted, and IndexFlatIP timed through it if it is there);
+      * the numpy oracle (oracle/), whose output doubles as the full-size parity check of the GPU step (parity_check) -
+        the checker, reported beside it.
+    The ranker legs are fed user_chunk users x 500 candidate rows per forward (the reference loops 500-row forwards,
+    inference.py:310-317: the 8-core survey probe of that form gave 38 recs/s)."""
+    import oracle
+    idx = oracle.search.FlatIndex(DIM)
+    idx.add(corpus_cpu)                                   # index build is not timed (nor is it on the GPU)
+    t0 = time.time()
+    ref = oracle.pipeline.recommend(tt_sd, rk_sd, idx, ad_table_cpu, uc[:n_users], un[:n_users], TOP_K, STAGE1_K,
+                                    user_chunk=user_chunk)
+    dt = time.time() - t0
+    threads = _host_threads()
+    numpy_leg = {"value": round(n_users / dt, 2), "unit": "recs/s", "cores": threads, "seconds": round(dt, 1),
+                 "what": "oracle/ (numpy fp32 BLAS + per-query sort): the parity checker"}
+    if not torch_leg:
+        return dict(numpy_leg, kind="port", sample=f"the first {n_users} users x {len(corpus_cpu)} ads through oracle/"), ref
+    try:
+        import faiss  # noqa: F401
+        have_faiss = True
+    except Exception:
+        have_faiss = False
+    faiss_leg = None
+    if have_faiss:                                        # never the case on this image; kept so that a box with faiss uses it
+        import faiss
+        fi = faiss.IndexFlatIP(DIM)
+        fi.add(corpus_cpu)
+        emb = oracle.search.normalize_l2(oracle.towers.user_tower(tt_sd, uc[:n_users], un[:n_users]))
+        t0 = time.time()
+        fi.search(emb, STAGE1_K)
+        faiss_leg = {"search_seconds": round(time.time() - t0, 3), "threads": faiss.omp_get_max_threads()}
+    tdt, tids = torch_cpu_pipeline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, uc, un, n_users, user_chunk)
+    same = float(np.mean([set(tids[b].tolist()) == set(ref[b]["ad_ids"]) for b in range(n_users)]))
+    tthreads = torch.get_num_threads()
+    return {"value": round(n_users / tdt, 2), "unit": "recs/s", "cores": int(tthreads), "kind": "port",
+            "sample": f"the first {n_users} users of the timed batch x {len(corpus_cpu)} ads end-to-end on PyTorch-CPU "
+                      f"(torch.get_num_threads() = {tthreads} of {os.cpu_count()} host CPUs): the drop-in modules' ATen "
+                      f"forwards (the reference's op sequence, eval mode, no_grad), IndexFlatIP restated as chunked Q@X^T + "
+                      f"torch.topk, ranker fed {user_chunk} users x {STAGE1_K} rows per forward, {tdt:.1f}s; faiss "
+                      + ("timed separately" if have_faiss else "unavailable - torch-CPU restatement"),
+            "top10_equal_to_numpy_oracle_frac": round(same, 4), "faiss": faiss_leg, "numpy_oracle": numpy_leg}, ref
 
 
 def parity_check(ref, out, n_users):
@@ -340,20 +423,21 @@ def main():
     dom_tag = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else ""
     stats0 = runner.short_list_stats() if world > 1 else None
 
-    def timed_region(fn):
+    def timed_region(fn, steps=None):
+        steps = args.steps if steps is None else steps
         barrier()
         _lib.profile_enable(True, only=dom_tag)  # HIP events around the dominant kernel's launches, on the launch stream
         # per-step HIP events on the launch stream (torch's current stream IS the stream every kernel is enqueued on,
         # _lib.stream_ptr): median / p95 of the step time
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(steps):
             marks[i].record()
             res = fn()
-        marks[args.steps].record()
+        marks[steps].record()
         barrier()
         dt_ = time.perf_counter() - t0
-        ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
         prof_ = _lib.profile_report()
         _lib.profile_enable(False)
         if world > 1:
@@ -381,6 +465,28 @@ def main():
                          "ms_per_step": round(dt2 / args.steps * 1000, 3), "unproven_queries": bad,
                          "note": "recommend_device(verify=False): the proof counter is read once after the region, not per step"}
     assert out["ad_ids"].shape[-1] == TOP_K
+
+    # The same step with the ranker on the STRICT fp32-MFMA engine (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain, the
+    # reference's arithmetic, transformer_ranker.py:355-378) - a second, labelled figure so that the headline's emulated
+    # fp32 (engine f16x3) is transparent.  5 timed steps after 2 warm-up steps; the default engine is restored afterwards.
+    strict = None
+    if not args.no_strict_fp32:
+        eng0 = rk.gemm_engine
+        rows_step = USERS_PER_GPU * STAGE1_K
+        rk.gemm_engine = "fp32"
+        try:
+            for _ in range(2):
+                step()
+            n_strict = max(1, min(5, args.steps))
+            dts, mss, _, _ = timed_region(step, n_strict)
+            strict = {"value": round(B_global * n_strict / dts, 1), "unit": "recs/s", "ms_per_step": round(dts / n_strict * 1000, 3),
+                      "steps": n_strict, "engine": rk.gemm_engine_for(rows_step),
+                      "note": "same step, TransformerRanker.gemm_engine = 'fp32': every ranker GEMM on the fp32 MFMA "
+                              "(exact fp32 products, fp32 accumulate); search and towers unchanged"}
+        finally:
+            rk.gemm_engine = eng0
+        step()                                          # re-pack the default engine (and its caches) before anything else
+        torch.cuda.synchronize(device)
 
     if rank == 0:
         ms_step = dt / args.steps * 1000
@@ -440,6 +546,16 @@ def main():
             if args.index == "flat":            # the oracle index is exact: only the exact engine is comparable
                 parity = parity_check(ref, out, n_cpu)
         default_cfg = n_ads == N_ADS and args.index == "flat"
+        eng_step = rk.gemm_engine_for(USERS_PER_GPU * STAGE1_K)
+        arithmetic = ("fp32 in / fp32 out everywhere; ranker (gemm_engine = " + rk.gemm_engine + f", x3_min_rows = {rk.x3_min_rows}: "
+                      f"the {USERS_PER_GPU * STAGE1_K}-row pass of a step runs engine {eng_step}, a single request's "
+                      f"{STAGE1_K}-row pass engine {rk.gemm_engine_for(STAGE1_K)}): "
+                      + ("operands scaled by powers of two and split into 2 fp16 planes, 3 fp16-MFMA products per MAC, fp32 "
+                         "accumulate - an EMULATION of fp32 (logit error vs float64 = 2-3x the fp32-MFMA engine's, "
+                         "profiles/r03_accuracy.json; the strict fp32-MFMA figure is `strict_fp32`); " if eng_step == "f16x3" else
+                         ("3 bf16 planes, 6 bf16-MFMA products per MAC, fp32 accumulate; " if eng_step == "bf16x6" else
+                          "fp32 MFMA; "))
+                      + "search: bf16-MFMA prefilter, fp32 re-score, certified exact; everything else fp32 MFMA / fp32 VALU")
         line = {"metric": "end-to-end recs/sec (1M ads d=256, top-500->10)" if default_cfg else
                           f"end-to-end recs/sec ({n_ads} ads d=256, {args.index}, top-500->10)", "value": round(value, 1),
                 "unit": "recs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -448,10 +564,7 @@ def main():
                 "step_ms_p95": round(step_ms[min(len(step_ms) - 1, int(np.ceil(0.95 * len(step_ms))) - 1)], 3),
                 "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "arithmetic": ("fp32 in / fp32 out everywhere; ranker passes of > 8192 rows (engine " + rk.gemm_engine + "): "
-                               "operands scaled by powers of two and split into 2 fp16 planes, 3 fp16-MFMA products per MAC, "
-                               "fp32 accumulate (logit error vs float64 = 2.2-2.7x the fp32-MFMA engine's, profiles/r02_accuracy.json); "
-                               "search: bf16-MFMA prefilter, fp32 re-score, certified exact; everything else fp32 MFMA / fp32 VALU"),
+                "arithmetic": arithmetic,
                 "config": {"workload": ("configs[2]: 1M synthetic ads d=256, UserTower batch=512/GPU, "
                                         "exact IP top-500, TransformerRanker(256,8 heads,3 layers) on 500 cands, top-10")
                            if default_cfg else f"{n_ads} ads ({corpus_kind} corpus), index={args.index}"
@@ -465,14 +578,14 @@ def main():
                            "exchange": exchange["kind"] if exchange else None,
                            "bytes_per_rank": exchange["bytes_per_rank"] if exchange else None,
                            "shard_lists": short_lists, "no_verify": no_verify},
-                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "kernels": kernels,
+                "strict_fp32": strict, "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "kernels": kernels,
                 "kernels_note": (f"per-kernel table from {n_pre} steps with HIP events around every tagged launch, run before "
                                  "the timed region; the timed region records events around the dominant kernel only "
                                  "(roofline.avg_launch_ms): an event pair costs the stream ~10 us of idle GPU per launch"),
                 "search": search}
+        if world == 1 and not args.no_latency_sweep:
+            line["e2e_latency_by_batch"] = latency_sweep(rec, uc, un, device)
         print(json.dumps(line), flush=True)
-    if args.sweep and rank == 0 and world == 1:
-        latency_sweep(rec, uc, un, device)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -539,7 +652,7 @@ def latency_sweep(rec, uc, un, device, reps=30):
             torch.cuda.synchronize(device)
             row["ms_per_call_hipgraph"] = round(e0.elapsed_time(e1) / reps, 3)
         rows.append(row)
-    print(json.dumps({"e2e_latency_by_batch": rows}), file=sys.stderr, flush=True)
+    return rows
 
 
 def search_sweep(index, device, reps=20):

@@ -68,12 +68,19 @@ def test_towers_large_batch_vs_oracle_crosses_row_passes():
     assert np.abs(np.linalg.norm(ae, axis=1) - 1).max() <= 1e-5
 
 
+@pytest.mark.parametrize("engine", ["f16x3", "fp32", "bf16x6"])
 @pytest.mark.parametrize("cross", list(cases.CROSS))
 @pytest.mark.parametrize("name", list(cases.CASES))
-def test_ranker_matches_reference_golden(name, cross, accuracy):
+def test_ranker_matches_reference_golden(name, cross, engine, accuracy):
+    """The reference's own outputs (tests/golden, generated from the imported transformer_ranker.py) against EVERY
+    engine: the default row-owner kernel (f16x3 takes every batch since x3_min_rows = 1), the strict fp32-MFMA engine
+    (it had lost its golden coverage when the default engine took the small batches) and bf16x6,
+    whose passes of <= 8192 rows are fp32-MFMA small shapes."""
     m, sd, _, batches = _ranker(name, cross)
+    m.gemm_engine = engine
     g = load_golden(f"ranker_{name}_{cross}.npz")
     for B in batches:
+        assert m.gemm_engine_for(B) == ("f16x3" if engine == "f16x3" else "fp32")
         with torch.no_grad():
             pred = m(_cu(g[f"B{B}_user_cat"]), _cu(g[f"B{B}_ad_cat"]), _cu(g[f"B{B}_user_num"]))
         assert list(pred) == ["ctr", "engagement", "revenue"]
@@ -81,8 +88,8 @@ def test_ranker_matches_reference_golden(name, cross, accuracy):
         for t in pred:
             assert pred[t].shape == (B,) and pred[t].dtype == torch.float32
             ok, err = cases.logit_close(pred[t].cpu().numpy(), g[f"B{B}_{t}"], cross, scale=scale)
-            accuracy(f"golden/{name}_{cross}/B{B}/{t}", m.gemm_engine_for(B), err)
-            assert ok, (name, cross, B, t, err)
+            accuracy(f"golden/{name}_{cross}/B{B}/{t}", engine if engine != "bf16x6" else "bf16x6(small=fp32)", err)
+            assert ok, (name, cross, engine, B, t, err)
 
 
 @pytest.mark.parametrize("cross", ["scaled", "randn"])

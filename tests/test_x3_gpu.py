@@ -83,7 +83,9 @@ def test_every_prefix_of_the_chain_matches_float64(cross, accuracy):
             accuracy(f"x3_prefix/demo_{cross}/{names[n - 1]}", f"f16x3/{VARIANT}", err / max(err32, 1e-30),
                      rel_err_vs_float64=err, numpy_fp32_rel_err_vs_float64=err32)
             assert np.isfinite(x).all(), names[n - 1]
-            assert err <= 4 * err32 + 2e-6, (names[n - 1], err, err32)
+            # worst recorded ratio 5.35 (L2.ffn_ln2, 16-row kernel, profiles/r02_accuracy.json): the bound is 6x with NO
+            # additive slack (the old `4x + 2e-6` passed only through its additive term)
+            assert err <= 6 * err32, (names[n - 1], err, err32)
         else:
             scale = cases.logit_scale(truth[-1])
             for ti, t in enumerate(oracle.ranker.TASKS):
