@@ -46,12 +46,52 @@ using x3::DEPTH;
 constexpr int WAVES = AMDREC_X3B_WAVES, ROWS_PER_WAVE = 16, ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
 constexpr int DMA_PER_WAVE = CHUNK_FRAGS / WAVES;     // 2 fragment sets per wave and chunk
 
-struct Ring {
+// Round-3 switches (bits of AMDREC_X3B_OPT; same-box A/Bs with tools/x3_probe.hip + tools/x3b_ab.sh, logs profiles/r03_x3b_*).
+// DEFAULT 71 = 1 | 2 | 4 | 64: 3.09 -> 2.96 ms per 256 000-row launch on the same box.
+//   1  hidden tile: relu + clamp as ONE v_med3_f32 in the unscaled domain, the scale folded into the plane split
+//      (v_fma_mixlo/hi_f16 pairs): 3 vector instructions per element instead of 8 (bit-identical)
+//   2  LayerNorm: the power-of-two unscale of the accumulators folded into the mean / deviation passes, the deviation
+//      kept in place: 5 instructions per element instead of 7 (bit-identical barring fp32 denormals)
+//   4  weight DMA by buffer_load ... lds with an SGPR chunk offset: no per-lane 64-bit address add, M0 written once per
+//      chunk (the instruction's immediate offset advances source and LDS destination together)
+//  64  the chunk's DMA pieces are issued one group AFTER the barrier (behind the first group's reads and MFMAs), so the
+//      matrix pipe has work queued while both waves of a SIMD sit in the memory-instruction issue
+//   (1 | 2 cut the non-MFMA vector instructions of an FFN step from 86 to 50 and move the time by 1 %; 64 alone moves
+//    nothing, 4 | 64 gives 3 %, all four 4.5 %: the kernel is not vector-issue-bound.)
+// Measured and NOT adopted (kept switchable where the code is small):
+//  16  static priority 1 for waves 4-7: +-0
+//  32  the next chunk's first fragment reads BEFORE the chunk's vmcnt wait + barrier: -2 % alone, +1.5 % on top of 64
+// 128  ONE barrier per TWO chunks (needs 64): +1 % - barriers are not what the waves wait for
+// 512  stagger (MI355X_MICROARCH "two waves that run the SAME program with one barrier per block"): waves 4-7 take the
+//      chunk's barrier in front of group 2 instead of group 0, as a second compile-time instantiation of the chain (RingT<2>):
+//      +2 % SLOWER, like its run-time-branch form (removed); also removed after losing their A/Bs: fragment prefetch
+//      carried across step / phase boundaries (16 more live registers: 19 -> 51 spilled, +2.5 %) and a third fragment
+//      buffer for a two-group read-ahead (+2.5 %, and no faster even with DMA and barrier compiled out: the fragment
+//      reads cost 0.5 ms of the launch by their LDS -> VGPR traffic, not by exposed latency).
+#ifndef AMDREC_X3B_OPT
+#define AMDREC_X3B_OPT 71
+#endif
+constexpr int OPT = AMDREC_X3B_OPT;
+#ifndef AMDREC_X3B_DMA_G0            // OPT & 64: groups (1..3) after whose reads DMA pieces 0 and 1 are issued
+#define AMDREC_X3B_DMA_G0 1
+#endif
+#ifndef AMDREC_X3B_DMA_G1
+#define AMDREC_X3B_DMA_G1 AMDREC_X3B_DMA_G0
+#endif
+constexpr int DMA_G0 = AMDREC_X3B_DMA_G0, DMA_G1 = AMDREC_X3B_DMA_G1;
+
+// LAG_: OPT & 512 (compile-time stagger): the group (0 or 2) of a chunk in front of which this wave half takes the chunk's
+// barrier - waves 0-3 run RingT<0>, waves 4-7 RingT<2>, two instantiations of the whole chain (no run-time branch splits
+// the unrolled GEMM blocks)
+template <int LAG_>
+struct RingT {
     const unsigned char* gsrc;
     lds_byte* lds_dma;
     lds_byte* lds_rd;
     int issued, total;
     int slot;                    // ring slot of the chunk being read
+    __amdgpu_buffer_rsrc_t rsrc; // OPT & 4: the whole stream as a raw buffer
+    uint32_t voff, soff0;        // OPT & 4: lane * 16; wave * DMA_PER_WAVE * FRAG_BYTES
     const lds_byte* cbase;       // its address for this lane (lds_rd + slot * CHUNK_BYTES)
     int gdyn;                    // group within the chunk, for read4_dyn only
     unsigned long long t_wait, t_bar, t_dma;     // DBG & 16 (diagnostic build only): cycles in the DMA wait / barrier / DMA issue
@@ -65,15 +105,52 @@ struct Ring {
         t_lds += b - a;
     }
 
+    template <int U>
+    __device__ __forceinline__ void dma_pieces(lds_byte* dst, uint32_t so) {
+        if constexpr (U < DMA_PER_WAVE) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, so,
+                                                     U * FRAG_BYTES, 0);
+            dma_pieces<U + 1>(dst, so);
+        }
+    }
+    // piece U of the chunk `issued` (pieces may be issued in different groups: the chunk counter moves with the last one)
+    template <int U>
+    __device__ __forceinline__ void issue_piece() {
+        static_assert(DMA_PER_WAVE == 2, "two pieces per wave and chunk");
+        if (DBG & 1) { if (U == DMA_PER_WAVE - 1) ++issued; return; }
+        const int c = issued < total ? issued : total - 1;
+        lds_byte* dst = lds_dma + (uint32_t)(issued % NBUF) * CHUNK_BYTES;
+        if (OPT & 4) {
+            const uint32_t so = __builtin_amdgcn_readfirstlane(soff0 + (uint32_t)c * CHUNK_BYTES);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, so,
+                                                     U * FRAG_BYTES, 0);
+        } else {
+            const unsigned char* src = gsrc + (size_t)c * CHUNK_BYTES;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + U * FRAG_BYTES),
+                                             (__attribute__((address_space(3))) void*)(dst + U * FRAG_BYTES), 16, 0, 0);
+        }
+        if (U == DMA_PER_WAVE - 1) ++issued;
+    }
+    template <int G>
+    __device__ __forceinline__ void issue_at_group() {
+        if (!(OPT & 64)) return;
+        if (G == DMA_G0) issue_piece<0>();
+        if (G == DMA_G1) issue_piece<1>();
+    }
     __device__ __forceinline__ void issue() {
         if (DBG & 1) { ++issued; return; }
         const int c = issued < total ? issued : total - 1;
-        const unsigned char* src = gsrc + (size_t)c * CHUNK_BYTES;
         lds_byte* dst = lds_dma + (uint32_t)(issued % NBUF) * CHUNK_BYTES;
+        if (OPT & 4) {
+            const uint32_t so = __builtin_amdgcn_readfirstlane(soff0 + (uint32_t)c * CHUNK_BYTES);
+            dma_pieces<0>(dst, so);
+        } else {
+            const unsigned char* src = gsrc + (size_t)c * CHUNK_BYTES;
 #pragma unroll
-        for (int u = 0; u < DMA_PER_WAVE; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * FRAG_BYTES),
-                                             (__attribute__((address_space(3))) void*)(dst + u * FRAG_BYTES), 16, 0, 0);
+            for (int u = 0; u < DMA_PER_WAVE; ++u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * FRAG_BYTES),
+                                                 (__attribute__((address_space(3))) void*)(dst + u * FRAG_BYTES), 16, 0, 0);
+        }
         ++issued;
     }
     __device__ __forceinline__ void certify_next() {
@@ -83,17 +160,29 @@ struct Ring {
             const unsigned long long b = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
             const unsigned long long c = __builtin_amdgcn_s_memtime();
-            issue();
+            if (!(OPT & 64)) issue();
             const unsigned long long d = __builtin_amdgcn_s_memtime();
             t_wait += b - a; t_bar += c - b; t_dma += d - c;
             return;
         }
-        if (!(DBG & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * (DEPTH - 1)) : "memory");
+        if (!(DBG & 1)) {
+            // OPT & 512 with the delayed DMA issue (64): a half whose barrier sits behind the issue group has already
+            // issued the pieces of one more chunk when it waits
+            constexpr int AHEAD = ((OPT & 512) != 0 && (OPT & 64) != 0) ? int(DMA_G0 < LAG_) + int(DMA_G1 < LAG_) : 0;
+            if (OPT & 128) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * (DEPTH - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * (DEPTH - 1) + AHEAD) : "memory");
+        }
         if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
-        issue();
+        if (!(OPT & 64)) issue();
     }
     __device__ __forceinline__ void start(const unsigned char* stream, int total_chunks, lds_byte* lds, int wave, int lane) {
         gsrc = stream + wave * DMA_PER_WAVE * FRAG_BYTES + lane * 16;
+        if (OPT & 4) {
+            rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(stream), 0,
+                                                     (uint32_t)total_chunks * CHUNK_BYTES, 0x00020000);
+            voff = (uint32_t)lane * 16;
+            soff0 = (uint32_t)wave * DMA_PER_WAVE * FRAG_BYTES;
+        }
         lds_dma = lds + wave * DMA_PER_WAVE * FRAG_BYTES;
         lds_rd = lds + lane * 16;
         issued = 0;
@@ -116,17 +205,28 @@ struct Ring {
     }
     // first read of a chunk: certify the one after it, move to its slot
     __device__ __forceinline__ void next_chunk() {
-        certify_next();
         slot = slot + 1 == NBUF ? 0 : slot + 1;
         cbase = lds_rd + (uint32_t)slot * CHUNK_BYTES;
+    }
+    // OPT & 512: the chunk's barrier (certify the next chunk, refill a free slot) in front of group LAG_ of every chunk:
+    // group 0 for waves 0-3, group 2 for waves 4-7.  Barrier j of either half: chunk j + 1 certified (it is read after
+    // the barrier by both), chunk j + DEPTH + 1 issued into the slot of chunk j - 2, which both halves have left.
+    template <int G>
+    __device__ __forceinline__ void staggered_barrier() {
+        if ((OPT & 512) && G == LAG_) certify_next();
     }
     // Fragment group G (0..3, a compile-time constant) of the current chunk: a chunk is 4 groups of 4 fragment sets, every
     // GEMM / FFN step starts on a chunk boundary and its loops are unrolled, so the position inside the chunk is known
     // at compile time: the four reads are one base register + immediate offsets, and the ring bookkeeping (slot
     // wrap-around, barrier, DMA) runs once per chunk instead of the per-group address arithmetic and boundary test.
-    template <int G>
+    template <int G8>                       // position in a PAIR of chunks (0..7); the group in its chunk is G8 & 3
     __device__ __forceinline__ void read4(f16x8 (&f)[4]) {
-        static_assert(G >= 0 && G < 4 && CHUNK_FRAGS == 16, "four groups of four fragment sets per chunk");
+        constexpr int G = G8 & 3;
+        constexpr bool BAR = (OPT & 512) ? false : ((OPT & 128) ? G8 == 0 : G == 0);      // this group opens a barrier interval
+        static_assert(G8 >= 0 && G8 < 8 && CHUNK_FRAGS == 16, "four groups of four fragment sets per chunk");
+        static_assert(!(OPT & 128) || ((OPT & 64) && DEPTH == 4), "OPT 128 needs OPT 64, no stagger, DEPTH 4");
+        staggered_barrier<G>();
+        if (BAR && !(OPT & 32)) certify_next();
         if (G == 0) next_chunk();
         if (DBG & 4) {
 #pragma unroll
@@ -136,12 +236,18 @@ struct Ring {
             for (int u = 0; u < 4; ++u)
                 f[u] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(cbase + (4 * G + u) * FRAG_BYTES);
         }
+        if (BAR && (OPT & 32)) certify_next();
+        issue_at_group<G>();
     }
     // the same with the group index at run time (heads: 10 groups per hidden tile); align() before the first use
     __device__ __forceinline__ void align() { gdyn = 0; }
     __device__ __forceinline__ void read4_dyn(f16x8 (&f)[4]) {
-        if (gdyn == 0) next_chunk();
-        const lds_byte* a = cbase + (uint32_t)gdyn * (4 * FRAG_BYTES);
+        const int g = gdyn & 3;
+        const bool bar = (OPT & 512) ? false : ((OPT & 128) ? gdyn == 0 : g == 0);
+        if ((OPT & 512) && g == LAG_) certify_next();
+        if (bar && !(OPT & 32)) certify_next();
+        if (g == 0) next_chunk();
+        const lds_byte* a = cbase + (uint32_t)g * (4 * FRAG_BYTES);
         if (DBG & 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(f[u]));
@@ -150,7 +256,12 @@ struct Ring {
             for (int u = 0; u < 4; ++u)
                 f[u] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(a + u * FRAG_BYTES);
         }
-        gdyn = (gdyn + 1) & 3;
+        if (bar && (OPT & 32)) certify_next();
+        if (OPT & 64) {
+            if (g == DMA_G0) issue_piece<0>();
+            if (g == DMA_G1) issue_piece<1>();
+        }
+        gdyn = (gdyn + 1) & 7;
     }
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
@@ -222,25 +333,26 @@ __device__ __forceinline__ void prepare(const f32x4 (&x)[16], float s, lds_cfloa
 }
 
 // groups I .. 63 of one 256 x 256 GEMM (group I = k-step I / 8, tile pair I % 8); `cur` holds group I's fragments
-template <int I>
-__device__ __forceinline__ void gemm256_groups(Ring& ring, f16x8 (&cur)[4], const f16x8 (&xh)[8], const f16x8 (&xl)[8],
+template <class RingX, int I>
+__device__ __forceinline__ void gemm256_groups(RingX& ring, f16x8 (&cur)[4], const f16x8 (&xh)[8], const f16x8 (&xl)[8],
                                                f32x4 (&acc)[16]) {
     constexpr int ks = I >> 3, tp = I & 7;
     f16x8 nxt[4];
-    if constexpr (I < 63) ring.template read4<(I + 1) & 3>(nxt);
+    if constexpr (I < 63) ring.template read4<(I + 1) & 7>(nxt);
     ring.timed_landed(cur);
     group6(cur, xh[ks], xl[ks], acc[2 * tp], acc[2 * tp + 1]);
-    if constexpr (I < 63) gemm256_groups<I + 1>(ring, nxt, xh, xl, acc);
+    if constexpr (I < 63) gemm256_groups<RingX, I + 1>(ring, nxt, xh, xl, acc);
 }
-template <int I0>
-__device__ __forceinline__ void gemm256_from(Ring& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4 (&acc)[16]) {
+template <class RingX, int I0>
+__device__ __forceinline__ void gemm256_from(RingX& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4 (&acc)[16]) {
     f16x8 cur[4];
     ring.template read4<0>(cur);
-    gemm256_groups<I0>(ring, cur, xh, xl, acc);
+    gemm256_groups<RingX, I0>(ring, cur, xh, xl, acc);
 }
 
-__device__ __forceinline__ void gemm256(Ring& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4 (&acc)[16]) {
-    gemm256_from<0>(ring, xh, xl, acc);
+template <class RingX>
+__device__ __forceinline__ void gemm256(RingX& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4 (&acc)[16]) {
+    gemm256_from<RingX, 0>(ring, xh, xl, acc);
 }
 
 __device__ __forceinline__ void layer_norm(f32x4 (&y)[16], lds_cfloat* pb, int gamma, int beta, float eps) {
@@ -267,7 +379,36 @@ __device__ __forceinline__ void layer_norm(f32x4 (&y)[16], lds_cfloat* pb, int g
     }
 }
 
-__device__ __forceinline__ void phase_attn_ln(Ring& ring, const Phase& P, f32x4 (&x)[16], lds_cfloat* pb) {
+// LayerNorm of y = acc * un (un a power of two: acc * un is exact, and so is sum(acc) * un == sum(acc * un) barring fp32
+// denormals): the unscale rides in the mean and in the deviation's fma, the deviation is kept in place
+__device__ __forceinline__ void layer_norm_scaled(const f32x4 (&acc)[16], float un, f32x4 (&y)[16], lds_cfloat* pb, int gamma,
+                                                  int beta, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[t][r];
+    const float mean = reduce_sum4(s) * un * (1.0f / 256.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = __builtin_fmaf(acc[t][r], un, -mean);
+            y[t][r] = d;
+            q += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(reduce_sum4(q) * (1.0f / 256.0f) + eps);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const f32x4 ga = param4(pb, gamma, t), be = param4(pb, beta, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[t][r] = y[t][r] * rstd * ga[r] + be[r];
+    }
+}
+
+template <class RingX>
+__device__ __forceinline__ void phase_attn_ln(RingX& ring, const Phase& P, f32x4 (&x)[16], lds_cfloat* pb) {
     float s, inv;
     row_scale(x, s, inv);
     f16x8 xh[8], xl[8];
@@ -275,6 +416,10 @@ __device__ __forceinline__ void phase_attn_ln(Ring& ring, const Phase& P, f32x4 
     prepare<true>(x, s, pb, P.b1, s * P.sw1, xh, xl, acc);
     gemm256(ring, xh, xl, acc);
     const float un = inv / P.sw1;
+    if (OPT & 2) {
+        layer_norm_scaled(acc, un, x, pb, P.gamma, P.beta, P.ln_eps);
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 16; ++t)
 #pragma unroll
@@ -283,12 +428,24 @@ __device__ __forceinline__ void phase_attn_ln(Ring& ring, const Phase& P, f32x4 
 }
 
 // hidden tile (two 16-feature accumulators = one k-step of stage 2) -> planes
-__device__ __forceinline__ void hidden_planes(const f32x4& a0, const f32x4& a1, float c, f16x8& hh, f16x8& hl) {
+// `lim` = 60000 / c (exact: c is a power of two)
+__device__ __forceinline__ void hidden_planes(const f32x4& a0, const f32x4& a1, float c, float lim, f16x8& hh, f16x8& hl) {
     if (DBG & 8) {
         asm volatile("" : "+v"(hh), "+v"(hl) : "v"(a0), "v"(a1));
         return;
     }
     f32x4 t0, t1;
+    if (OPT & 1) {
+        // min(max(a, 0) * c, 60000) == med3(a, 0, 60000 / c) * c for a power-of-two c: relu and clamp are one instruction
+        // in the unscaled domain and the scale rides in the split's fma_mix instructions
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t0[r] = __builtin_amdgcn_fmed3f(a0[r], 0.f, lim);
+            t1[r] = __builtin_amdgcn_fmed3f(a1[r], 0.f, lim);
+        }
+        split8(t0, t1, c, hh, hl);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         t0[r] = fminf(fmaxf(a0[r], 0.f) * c, 60000.f);
@@ -305,49 +462,54 @@ __device__ __forceinline__ void init_pair(f32x4& a0, f32x4& a1, lds_cfloat* pb, 
     }
 }
 
-template <bool S1, bool S2, int GI>
-__device__ __forceinline__ void ffn_groups(Ring& ring, f16x8 (&cur)[4], const f16x8 (&xh)[8], const f16x8 (&xl)[8],
+template <class RingX, bool S1, bool S2, int GI>
+__device__ __forceinline__ void ffn_groups(RingX& ring, f16x8 (&cur)[4], const f16x8 (&xh)[8], const f16x8 (&xl)[8],
                                            f32x4& a10, f32x4& a11, f32x4 (&acc2)[16], const f16x8& hh, const f16x8& hl) {
     constexpr int NG = (S1 ? 8 : 0) + (S2 ? 8 : 0);          // groups in this step (a multiple of 4: whole chunks)
     constexpr bool is1 = S1 && (!S2 || (GI & 1) == 0);
     constexpr int u = (S1 && S2) ? GI >> 1 : GI;
     f16x8 nxt[4];
-    if constexpr (GI < NG - 1) ring.template read4<(GI + 1) & 3>(nxt);
+    if constexpr (GI < NG - 1) ring.template read4<(GI + 1) & 7>(nxt);
     ring.timed_landed(cur);
     if constexpr (is1) group6(cur, xh[u], xl[u], a10, a11);
     else group6(cur, hh, hl, acc2[2 * u], acc2[2 * u + 1]);
-    if constexpr (GI < NG - 1) ffn_groups<S1, S2, GI + 1>(ring, nxt, xh, xl, a10, a11, acc2, hh, hl);
+    if constexpr (GI < NG - 1) ffn_groups<RingX, S1, S2, GI + 1>(ring, nxt, xh, xl, a10, a11, acc2, hh, hl);
 }
 
 // One FFN step: 8 x { stage-1 group (W_1 tiles 2t, 2t+1 at ks = u), stage-2 group (W_2 tiles 2u, 2u+1 at k-step t-1) }
-template <bool S1, bool S2>
-__device__ __forceinline__ void ffn_step(Ring& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4& a10, f32x4& a11,
+template <class RingX, bool S1, bool S2>
+__device__ __forceinline__ void ffn_step(RingX& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4& a10, f32x4& a11,
                                          f32x4 (&acc2)[16], const f16x8& hh, const f16x8& hl) {
     f16x8 cur[4];
     ring.template read4<0>(cur);
-    ffn_groups<S1, S2, 0>(ring, cur, xh, xl, a10, a11, acc2, hh, hl);
+    ffn_groups<RingX, S1, S2, 0>(ring, cur, xh, xl, a10, a11, acc2, hh, hl);
 }
 
-__device__ __forceinline__ void phase_ffn_ln(Ring& ring, const Phase& P, f32x4 (&x)[16], lds_cfloat* pb) {
+template <class RingX>
+__device__ __forceinline__ void phase_ffn_ln(RingX& ring, const Phase& P, f32x4 (&x)[16], lds_cfloat* pb) {
     float s, inv;
     row_scale(x, s, inv);
     f16x8 xh[8], xl[8];
     const float sh = x3::hidden_scale(fmaf(P.hn * 8192.0f, inv, P.hb));
     f32x4 acc2[16];
     prepare<true>(x, s, pb, P.b2, P.sw2 * sh, xh, xl, acc2);
-    const float b1s = s * P.sw1, c1 = sh * inv / P.sw1;
+    const float b1s = s * P.sw1, c1 = sh * inv / P.sw1, lim1 = 60000.f / c1;
     f32x4 a10, a11;
     f16x8 hh, hl;
     init_pair(a10, a11, pb, P.b1, 0, b1s);
-    ffn_step<true, false>(ring, xh, xl, a10, a11, acc2, hh, hl);
+    ffn_step<RingX, true, false>(ring, xh, xl, a10, a11, acc2, hh, hl);
     for (int t = 1; t < P.n_steps; ++t) {
-        hidden_planes(a10, a11, c1, hh, hl);
+        hidden_planes(a10, a11, c1, lim1, hh, hl);
         init_pair(a10, a11, pb, P.b1, 2 * t, b1s);
-        ffn_step<true, true>(ring, xh, xl, a10, a11, acc2, hh, hl);
+        ffn_step<RingX, true, true>(ring, xh, xl, a10, a11, acc2, hh, hl);
     }
-    hidden_planes(a10, a11, c1, hh, hl);
-    ffn_step<false, true>(ring, xh, xl, a10, a11, acc2, hh, hl);
+    hidden_planes(a10, a11, c1, lim1, hh, hl);
+    ffn_step<RingX, false, true>(ring, xh, xl, a10, a11, acc2, hh, hl);
     const float un = 1.0f / (P.sw2 * sh);
+    if (OPT & 2) {
+        layer_norm_scaled(acc2, un, x, pb, P.gamma, P.beta, P.ln_eps);
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 16; ++t)
 #pragma unroll
@@ -373,7 +535,8 @@ __device__ __forceinline__ void store_rows(const f32x4 (&x)[16], float* row_ptr,
     for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(row_ptr + 16 * t + 4 * g) = x[t];
 }
 
-__device__ __forceinline__ void phase_cross(Ring& ring, const Phase& P, f32x4 (&xl_)[16], const float* x0_row, int g,
+template <class RingX>
+__device__ __forceinline__ void phase_cross(RingX& ring, const Phase& P, f32x4 (&xl_)[16], const float* x0_row, int g,
                                             lds_cfloat* pb) {
     float s, inv;
     row_scale(xl_, s, inv);
@@ -390,7 +553,8 @@ __device__ __forceinline__ void phase_cross(Ring& ring, const Phase& P, f32x4 (&
     }
 }
 
-__device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const Phase& P, const f32x4 (&x)[16], float* out,
+template <class RingX>
+__device__ __forceinline__ void phase_heads(RingX& ring, const Program& G, const Phase& P, const f32x4 (&x)[16], float* out,
                                             long long ld_out, long long row, bool row_ok, int g, lds_cfloat* pb) {
     float s, inv;
     row_scale(x, s, inv);
@@ -398,7 +562,7 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) split8(x[2 * ks], x[2 * ks + 1], s, xh[ks], xl[ks]);
     const float sh = x3::hidden_scale(fmaf(P.hn * 8192.0f, inv, P.hb));
-    const float b1s = s * P.sw1, c1 = sh * inv / P.sw1, un2 = 1.0f / (P.sw2 * sh);
+    const float b1s = s * P.sw1, c1 = sh * inv / P.sw1, un2 = 1.0f / (P.sw2 * sh), lim1 = 60000.f / c1;
     ring.align();                                             // the phase starts on a chunk boundary
     for (int task = 0; task < P.n_tasks; ++task) {
         f32x4 acc2[4];
@@ -408,6 +572,7 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
             f32x4 a10, a11;
             init_pair(a10, a11, pb, P.b1 + task * P.n_steps * 32, 2 * t, b1s);
             f16x8 cur[4], nxt[4];
+            f16x8 hh, hl;
             ring.read4_dyn(cur);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -418,8 +583,7 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
                     for (int v = 0; v < 4; ++v) cur[v] = nxt[v];
                 }
             }
-            f16x8 hh, hl;
-            hidden_planes(a10, a11, c1, hh, hl);
+            hidden_planes(a10, a11, c1, lim1, hh, hl);
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 ring.read4_dyn(cur);
@@ -438,26 +602,16 @@ __device__ __forceinline__ void phase_heads(Ring& ring, const Program& G, const 
     }
 }
 
-__global__ __launch_bounds__(64 * WAVES, 2) void ranker_x3b_kernel(Program G, Input in, long long rows, float* scratch,
-                                                            float* x_out, long long ld_xout, float* logits,
-                                                            long long ld_logits) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// everything after the parameter blob is in LDS: ring start, row load, the phases, logits
+template <class RingX>
+__device__ __forceinline__ void run_chain(const Program& G, const Input& in, long long rows, float* scratch, float* x_out,
+                                          long long ld_xout, float* logits, long long ld_logits, unsigned char* smem, int wave,
+                                          int lane, lds_cfloat* pb) {
     const int g = lane >> 4, q = lane & 15;
     const long long row = (long long)blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE + q;
     const bool row_ok = row < rows;
     const long long rowc = row_ok ? row : rows - 1;
-
-    lds_byte* pbase = (lds_byte*)smem + RING_BYTES;
-    for (int o = 0; o + wave * 1024 < G.n_params * 4; o += WAVES * 1024)  // WAVES x 1 KB per pass; n_params % 1024 == 0
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(
-                                             reinterpret_cast<const unsigned char*>(G.params) + o + tid * 16),
-                                         (__attribute__((address_space(3))) void*)(pbase + o + wave * 1024), 16, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_cfloat* pb = reinterpret_cast<lds_cfloat*>(pbase) + 4 * g;
-
-    Ring ring;
+    RingX ring;
     const unsigned long long t_begin = (DBG & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
     ring.start(G.stream, G.total_chunks, (lds_byte*)smem, wave, lane);
 
@@ -499,6 +653,29 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ranker_x3b_kernel(Program G, In
         dbg[2] = (DBG & 32) ? (float)ring.t_cal : (float)ring.t_bar;
         dbg[3] = (float)ring.t_dma;
     }
+}
+
+__global__ __launch_bounds__(64 * WAVES, 2) void ranker_x3b_kernel(Program G, Input in, long long rows, float* scratch,
+                                                            float* x_out, long long ld_xout, float* logits,
+                                                            long long ld_logits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+
+    lds_byte* pbase = (lds_byte*)smem + RING_BYTES;
+    for (int o = 0; o + wave * 1024 < G.n_params * 4; o += WAVES * 1024)  // WAVES x 1 KB per pass; n_params % 1024 == 0
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(
+                                             reinterpret_cast<const unsigned char*>(G.params) + o + tid * 16),
+                                         (__attribute__((address_space(3))) void*)(pbase + o + wave * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_cfloat* pb = reinterpret_cast<lds_cfloat*>(pbase) + 4 * g;
+
+    if ((OPT & 16) && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+    if ((OPT & 512) && wave >= WAVES / 2)
+        run_chain<RingT<2>>(G, in, rows, scratch, x_out, ld_xout, logits, ld_logits, smem, wave, lane, pb);
+    else
+        run_chain<RingT<0>>(G, in, rows, scratch, x_out, ld_xout, logits, ld_logits, smem, wave, lane, pb);
 }
 
 }  // namespace x3b
