@@ -69,6 +69,8 @@ static int x3_build(const amdrec_ranker_params* p, int n_phases, x3::Program& G)
     return AMDREC_OK;
 }
 
+constexpr long long X3B4_MAX_ROWS = 256ll * 64;      // one 64-row workgroup per CU
+
 static size_t x3_scratch_bytes(long long rows) {
     return (size_t)((rows + x3::ROWS_PER_WG - 1) / x3::ROWS_PER_WG) * x3::ROWS_PER_WG * 256 * 4;
 }
@@ -81,9 +83,16 @@ static int x3_launch(const x3::Program& G, const x3::Input& in, long long rows, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(x3b::ranker_x3b_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(x3b4::ranker_x3b_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
         attr_done.mark();
     }
-    const unsigned grid = (unsigned)((rows + x3::ROWS_PER_WG - 1) / x3::ROWS_PER_WG);
+    // 16-row variant, small passes: 64-row workgroups of four waves (one per SIMD) - a pass that fits the chip once in that
+    // shape (<= 256 CUs x 64 rows) finishes in ~0.7 of the 128-row shape's time (one request's 500 rows: 0.20 against
+    // 0.28 ms, profiles/r03_x3b_waves.log); beyond it the 128-row shape's two waves per SIMD win
+    const bool small = variant == 16 && rows <= X3B4_MAX_ROWS;
+    const int rows_wg = small ? x3b4::ROWS_PER_WG : x3::ROWS_PER_WG;
+    const unsigned grid = (unsigned)((rows + rows_wg - 1) / rows_wg);
     {
         // algorithmic FLOPs: 2 * rows * sum over the phases' weight elements (bench.py prices them against bf16 MFMA / 3)
         double w = 0;
@@ -93,9 +102,12 @@ static int x3_launch(const x3::Program& G, const x3::Input& in, long long rows, 
             else if (P.type == x3::PH_FFN_LN) w += 2.0 * 256.0 * 32.0 * P.n_steps;
             else w += (double)P.n_tasks * (256.0 * 32.0 * P.n_steps + 64.0 * 32.0 * P.n_steps + 64.0);
         }
-        ProfScope prof(variant == 16 ? "ranker_rowowner16_128_x3" : "ranker_rowowner_128_x3", 2.0 * (double)rows * w,
-                       (double)rows * (1024.0 + 12.0), st);
-        if (variant == 16)
+        ProfScope prof(small ? "ranker_rowowner16_64_x3" : (variant == 16 ? "ranker_rowowner16_128_x3" : "ranker_rowowner_128_x3"),
+                       2.0 * (double)rows * w, (double)rows * (1024.0 + 12.0), st);
+        if (small)
+            hipLaunchKernelGGL(x3b4::ranker_x3b_kernel, dim3(grid), dim3(64 * x3b4::WAVES), x3::RING_BYTES + x3::PARAM_FLOATS * 4, st,
+                               G, in, rows, scratch, x_out, ld_xout, logits, ld_logits);
+        else if (variant == 16)
             hipLaunchKernelGGL(x3b::ranker_x3b_kernel, dim3(grid), dim3(512), x3::RING_BYTES + x3::PARAM_FLOATS * 4, st, G, in,
                                rows, scratch, x_out, ld_xout, logits, ld_logits);
         else

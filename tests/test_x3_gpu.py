@@ -61,11 +61,12 @@ def _prefix(m, X, n_phases):
     return x_out.cpu().numpy(), logits.cpu().numpy()
 
 
+@pytest.mark.parametrize("rows", [128 * 3 + 45,            # <= 16384 rows: the 64-row workgroup shape (x3b4), ragged tail
+                                  16384 + 128 * 3 + 45])   # beyond: the 128-row shape (x3b), three full workgroups + a ragged one
 @pytest.mark.parametrize("cross", ["scaled", "randn"])
-def test_every_prefix_of_the_chain_matches_float64(cross, accuracy):
+def test_every_prefix_of_the_chain_matches_float64(cross, rows, accuracy):
     m, sd, dims = _model("demo", cross)
     assert m.gemm_engine == "f16x3" and m.gemm_engine_for(10_000) == "f16x3"
-    rows = 128 * 3 + 45                                  # three full workgroups and a ragged one
     X = _projected_rows(sd, dims, rows, seed=41)
     truth = oracle.ranker.chain_states(sd, X, dtype=np.float64)
     f32 = oracle.ranker.chain_states(sd, X, dtype=np.float32)
@@ -80,7 +81,7 @@ def test_every_prefix_of_the_chain_matches_float64(cross, accuracy):
             scale = np.abs(ref).max(axis=1, keepdims=True)            # per-row magnitude
             err = float((np.abs(x - ref) / scale).max())
             err32 = float((np.abs(f32[n - 1] - ref) / scale).max())   # the numpy fp32 evaluation of the same prefix
-            accuracy(f"x3_prefix/demo_{cross}/{names[n - 1]}", f"f16x3/{VARIANT}", err / max(err32, 1e-30),
+            accuracy(f"x3_prefix/demo_{cross}/rows{rows}/{names[n - 1]}", f"f16x3/{VARIANT}", err / max(err32, 1e-30),
                      rel_err_vs_float64=err, numpy_fp32_rel_err_vs_float64=err32)
             assert np.isfinite(x).all(), names[n - 1]
             # worst recorded ratio 5.35 (L2.ffn_ln2, 16-row kernel, profiles/r02_accuracy.json): the bound is 6x with NO
@@ -90,7 +91,7 @@ def test_every_prefix_of_the_chain_matches_float64(cross, accuracy):
             scale = cases.logit_scale(truth[-1])
             for ti, t in enumerate(oracle.ranker.TASKS):
                 ok, e = cases.logit_close(logits[ti], truth[-1][t], cross, scale=scale)
-                accuracy(f"x3_prefix/demo_{cross}/heads/{t}", f"f16x3/{VARIANT}", e)
+                accuracy(f"x3_prefix/demo_{cross}/rows{rows}/heads/{t}", f"f16x3/{VARIANT}", e)
                 assert ok, (t, e)
 
 

@@ -15,10 +15,13 @@
 #ifndef PROBE_PARAM_FLOATS
 #define PROBE_PARAM_FLOATS x3::PARAM_FLOATS
 #endif
+#ifndef AMDREC_X3_PROBE_NS           // x3b: 8 waves x 16 rows per workgroup; x3b4: 4 waves (the small-pass shape)
+#define AMDREC_X3_PROBE_NS x3b
+#endif
 #if AMDREC_X3_VARIANT == 16
-#define KERNEL x3b::ranker_x3b_kernel
-#define NTHREADS (64 * x3b::WAVES)
-#define ROWS_WG (16 * x3b::WAVES)
+#define KERNEL AMDREC_X3_PROBE_NS::ranker_x3b_kernel
+#define NTHREADS (64 * AMDREC_X3_PROBE_NS::WAVES)
+#define ROWS_WG (16 * AMDREC_X3_PROBE_NS::WAVES)
 #else
 #define KERNEL x3::ranker_x3_kernel
 #define NTHREADS 256
