@@ -197,10 +197,16 @@ __global__ __launch_bounds__(512) void finalize_kernel(const unsigned long long*
     write_result(keys, c, k, q, outD, outI, pos_offset);
 }
 
-// step 5a: exact streaming scan of one corpus slice for a failed query
-__global__ __launch_bounds__(512) void fixup_scan_kernel(const float* X, long long ldx, long long nrows, int d,
-                                                         const float* Q, long long ldq, const int* fail, int nq,
-                                                         int k, int nslices, unsigned long long* scratch) {
+// step 5: exact streaming scan of one corpus slice for a failed query; the block that finishes a query's LAST slice (a
+// ticket per query, agent-scope release / acquire around it as in cdna_hip_programming.md "in-launch split-K reduction")
+// merges the slices and writes the result.  One launch: in the common case - no failed query - it is the only cost of the
+// fix-up, and two empty launches cost 8 us of a 140 us single-query search.
+__global__ __launch_bounds__(512) void fixup_kernel(const float* X, long long ldx, long long nrows, int d,
+                                                    const float* Q, long long ldq, const int* fail, int nq,
+                                                    int k, int nslices, unsigned long long* scratch, int* ticket,
+                                                    float* outD, long long* outI, long long pos_offset) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // merge: k * nslices keys (<= CAND_CAP)
+    __shared__ int last_sh;
     __shared__ __attribute__((aligned(16))) unsigned long long buf[FIX_BUF];
     __shared__ __attribute__((aligned(16))) float qv[2048];
     __shared__ unsigned long long thr;
@@ -274,27 +280,29 @@ __global__ __launch_bounds__(512) void fixup_scan_kernel(const float* X, long lo
     const int c = count;
     unsigned long long* dst = scratch + ((long long)q * nslices + s) * k;
     for (int i = tid; i < k; i += 512) dst[i] = (i < c) ? buf[i] : 0ull;
-    __syncthreads();                                           // before the next query resets count / thr / buf
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slice stores are out
+    __syncthreads();                                           // ... every wave's; also: before count / thr / buf are reset
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the fence's own wait may be dropped: keep this one)
+        const int t = __hip_atomic_fetch_add(&ticket[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_sh = t == nslices - 1;
+        if (t == nslices - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
-}
-
-// step 5b: merge the slices of a failed query
-__global__ __launch_bounds__(512) void fixup_merge_kernel(const unsigned long long* scratch, const int* fail, int nq,
-                                                          int k, int nslices, float* outD, long long* outI,
-                                                          long long pos_offset) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-    if (fail[nq] == 0) return;
-    const int total = k * nslices;
-    int P = 2;
-    while (P < total) P <<= 1;
-    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
-        if (!fail[q]) continue;
-        for (int i = threadIdx.x; i < P; i += blockDim.x)
-            keys[i] = (i < total) ? scratch[(long long)q * total + i] : 0ull;
+    __syncthreads();
+    if (last_sh) {                                             // block-uniform: merge the query's slices
+        const int total = k * nslices;
+        int P = 2;
+        while (P < total) P <<= 1;
+        for (int i = tid; i < P; i += 512) keys[i] = (i < total) ? scratch[(long long)q * total + i] : 0ull;
         __syncthreads();
         bitonic_desc(keys, P);
         write_result(keys, total < k ? total : k, k, q, outD, outI, pos_offset);
-        __syncthreads();
+    }
+    __syncthreads();
     }
 }
 
@@ -365,6 +373,47 @@ __global__ __launch_bounds__(512) void topk_merge_kernel(const char* scores, con
 //    spills to the query's overflow block through a global counter; finalize_mixed_kernel reads the segments in place.
 // Each corpus byte is read from HBM once per 512 queries; waves whose queries lie beyond nq skip their MFMAs, so a
 // small batch runs at the HBM rate and a full one at the bf16 MFMA rate.
+// tau of ONE query by ONE wave from its row of group maxima gm[0 .. n) (n % 4 == 0, 16-byte aligned): float4 chunk i
+// belongs to group i % 256; tau = the r-th largest of the 256 group maxima (r <= 256; fewer than r finite maxima -> -inf;
+// NaN never wins a maximum).  The same estimator as sample_threshold_kernel: expected sample rank of the result r + r^2/512,
+// i.e. the candidate count errs high, far inside the capacity.  Selection without LDS: a lane holds 4 of the 256 maxima
+// as order-preserving 32-bit keys; the r-th largest is built bit by bit (largest T with #{key >= T} >= r), each count a
+// ballot + scalar popcount per register - ~500 instructions, where ranking every value against all 256 through LDS cost
+// 25 us per query.
+__device__ __forceinline__ float wave_tau(const float* row, long long n, int r, int lane) {
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const long long nch = n >> 2;
+    for (long long c0 = 0; c0 < nch; c0 += 512) {           // eight independent 16-byte loads in flight per lane
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = c0 + 64 * u + lane;
+            v[u] = i < nch ? *reinterpret_cast<const f32x4*>(row + 4 * i) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[u & 3] = v[u][e] > m[u & 3] ? v[u][e] : m[u & 3];     // chunk i -> group i % 256
+    }
+    uint32_t key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t b = __float_as_uint(m[u]);
+        key[u] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);     // unsigned order == float order (no NaN among the maxima)
+    }
+    uint32_t T = 0u;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t c = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt += __builtin_popcountll(__ballot(key[u] >= c));
+        if (cnt >= r) T = c;                                  // wave-uniform
+    }
+    const uint32_t b = (T & 0x80000000u) ? (T & 0x7fffffffu) : ~T;
+    return __uint_as_float(b);
+}
+
 constexpr int SCAN_ROWS = 128;          // corpus rows per LDS tile
 constexpr int SCAN_WHITS = 128;         // hit-list entries per wave and tile (expected ~11; overflow -> direct append)
 constexpr int SCAN_QGROUP = 512;        // queries per workgroup (8 waves x 64)
@@ -380,8 +429,10 @@ __device__ __forceinline__ void lds_store_hit_opaque(uint32_t key_addr, unsigned
 template <int KS>                       // KS = dim / 16 in {2, 4, 8, 16}
 __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __restrict__ X16, long long ld16,
                                                              long long nrows, const uint16_t* __restrict__ Q16, int nq,
-                                                             const float* __restrict__ tau, unsigned long long* cand,
-                                                             int* segcnt, int* ocnt, int seg_cap, int nx) {
+                                                             float* __restrict__ tau, unsigned long long* cand,
+                                                             int* segcnt, int* ocnt, int seg_cap, int nx,
+                                                             const float* __restrict__ gm, long long ldm, long long gm_n,
+                                                             int rank) {
     constexpr int CPR = 2 * KS;                                  // 16-byte chunks per row
     constexpr int FM = CPR < 16 ? CPR - 1 : 15;                  // swizzle mask
     constexpr int FS = CPR >= 16 ? 0 : (CPR == 8 ? 1 : 2);       // swizzle row shift
@@ -414,14 +465,13 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     const int ntiles = (int)((nrows + SCAN_ROWS - 1) / SCAN_ROWS);
     const int nrows_i = (int)nrows;                                                // < 2^31 (checked by the entry point)
 
-    // query fragments + thresholds (clamped rows; columns >= nq get tau = NaN)
+    // query fragments (clamped rows); the thresholds tq are filled in below, once they are known
     bf16x8 qf[2][KS];
     float tq[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + j * 32 + frow;
         const int qc = q < nq ? q : nq - 1;
-        tq[j] = (q < nq) ? tau[q] : __builtin_nanf("");            // NaN: no score compares >= it
 #pragma unroll
         for (int s_ = 0; s_ < KS; ++s_)
             qf[j][s_] = *reinterpret_cast<const bf16x8*>(Q16 + (long long)qc * (16 * KS) + (2 * s_ + fh) * 8);
@@ -530,8 +580,26 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
 
     int t = bx;
     if (t < ntiles) dma(t, 0);
+    // Thresholds.  Batches of <= 8 queries (gm != nullptr): no threshold launch - while the first tile is in flight wave w
+    // computes tau of query w from the sample's group maxima (wave_tau: a deterministic function of gm, so every workgroup
+    // arrives at the same value), workgroup 0 publishes it for the finalize.  Columns >= nq get NaN: no score compares >= it.
+    __shared__ float tau_sh[8];
+    if (gm != nullptr) {
+        if (w < nq) {
+            const float tw = wave_tau(gm + (long long)w * ldm, gm_n, rank, lane);
+            if (lane == 0) {
+                tau_sh[w] = tw;
+                if (bx == 0) tau[w] = tw;
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                               // first tile landed
+    __syncthreads();                                               // first tile landed, tau_sh written
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = q0 + j * 32 + frow;
+        tq[j] = (q < nq) ? (gm != nullptr ? tau_sh[q] : tau[q]) : __builtin_nanf("");
+    }
     int it = 0, wprev = 0;                                         // wprev: hits of the previous tile awaiting their append
     for (; t < ntiles; t += nx, ++it) {
         const int buf = it & 1;
@@ -582,6 +650,158 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     if (tid < nqg) segcnt[(long long)(qbase + tid) * nx + bx] = lcnt[tid];      // every (query, segment) count is written: no memset
 }
 
+// ---- fused query conversion + sample pass of the mixed search (dims 32 / 64 / 128 / 256) ---------------------------
+// One launch instead of three (bf16_rows_kernel for the queries, a generic-tile GEMM that stored the DENSE sample score
+// matrix - 94 MB at 512 queries x 46k sample rows - and the threshold kernel that read it back): the same streaming
+// structure as scan_filter_kernel over an evenly spaced subset of 128-row corpus tiles, with
+//  * the queries converted fp32 -> bf16 in the prologue (same rounding as bf16_rows_kernel; the workgroups with bx == 0
+//    also write the bf16 rows the corpus pass reads, and every workgroup clears its share of the search's counters);
+//  * the epilogue keeping only MAXIMA: per (query, 16- / 4- / 1-row group) one float in gm[nq][ldm] - the threshold only
+//    needs the r-th largest of ~256 group maxima of the sample (see wave_tau), and a maximum of maxima is the maximum.
+// SUB = values per lane, query tile and 32-row quarter: 1 (16-row groups), 4 (4-row groups), 16 (every score: corpora so
+// small that coarser groups would leave fewer than ~1000 columns).  Column of a value: ((tile * 4 + quarter) * 2 + fh) * SUB + i.
+template <int KS, int SUB>
+__global__ __launch_bounds__(512, 1) void sample_max_kernel(const uint16_t* __restrict__ X16, long long ld16, int tstride,
+                                                            int n_tiles, const float* __restrict__ Q, long long ldq, int nq,
+                                                            uint16_t* __restrict__ Q16, float* __restrict__ gm, long long ldm,
+                                                            int nx, int* zero, long long n_zero) {
+    constexpr int CPR = 2 * KS, FM = CPR < 16 ? CPR - 1 : 15, FS = CPR >= 16 ? 0 : (CPR == 8 ? 1 : 2);
+    constexpr int TILE_CHUNKS = SCAN_ROWS * CPR, PASSES = TILE_CHUNKS / 512, AHEAD = KS < 4 ? KS : 4, RPP = 512 / CPR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                      // [2][TILE_CHUNKS * 16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    const int bx = blockIdx.x % nx, by = blockIdx.x / nx;
+    for (long long i = (long long)blockIdx.x * 512 + tid; i < n_zero; i += (long long)gridDim.x * 512) zero[i] = 0;
+    // the same work split as the corpus pass: waves without queries of their own take a share of the tile's rows
+    const int nqg = nq - by * SCAN_QGROUP < SCAN_QGROUP ? nq - by * SCAN_QGROUP : SCAN_QGROUP;
+    const int qsh = nqg <= 64 ? 0 : (nqg <= 128 ? 1 : (nqg <= 256 ? 2 : 3));
+    const int parts = qsh <= 1 ? 4 : (qsh == 2 ? 2 : 1);
+    const int part = w >> qsh;
+    const int q0 = by * SCAN_QGROUP + (w & ((1 << qsh) - 1)) * 64;
+    const bool active = q0 < nq && part < parts;
+    const int rq_begin = part * (4 / parts), rq_end = rq_begin + 4 / parts;
+    const bool second = q0 + 32 < nq;
+
+    // query fragments: 8 consecutive floats -> 8 bf16 (round to nearest even, NaN kept: bf16_rows_kernel's rounding)
+    bf16x8 qf[2][KS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = q0 + j * 32 + frow;
+        const int qc = q < nq ? q : nq - 1;
+        const bool wr = bx == 0 && part == 0 && q < nq;              // exactly one lane pair per (query, k-step) writes
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            const float* src = Q + (long long)qc * ldq + (2 * s_ + fh) * 8;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+            uint32_t h[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = e < 4 ? v0[e & 3] : v1[e & 3];
+                const uint32_t u = __float_as_uint(v);
+                h[e] = (v != v) ? 0x7fc0u : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            }
+            const u32x4 pk{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            qf[j][s_] = __builtin_bit_cast(bf16x8, pk);
+            if (wr && q0 + j * 32 < nq) *reinterpret_cast<u32x4*>(Q16 + (long long)q * (16 * KS) + (2 * s_ + fh) * 8) = pk;
+        }
+    }
+    // tile DMA: the lane map of scan_filter_kernel (sample tiles are whole tiles: no clamped path)
+    const int drow = tid / CPR;
+    const uint32_t lane_off = (uint32_t)(drow * (int)ld16 * 2 + (((tid % CPR) ^ ((drow >> FS) & FM)) * 16));
+    auto dma = [&](int st_, int buf) {
+        const long long row0 = (long long)st_ * tstride * SCAN_ROWS;
+        unsigned char* lbase = lds + (size_t)buf * TILE_CHUNKS * 16 + (size_t)(w * 64) * 16;
+        const unsigned char* gb = reinterpret_cast<const unsigned char*>(X16) + row0 * ld16 * 2;
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const unsigned char* g = gb + (long long)u * RPP * ld16 * 2 + lane_off;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lbase + (size_t)u * 512 * 16), 16, 0, 0);
+        }
+    };
+    // both buffers are requested up front (a workgroup of a 1M-row search has one or two tiles: their latencies overlap);
+    // from the third tile on a buffer is re-filled as soon as every wave has left it
+    int t = bx;
+    if (t < n_tiles) dma(t, 0);
+    if (t + nx < n_tiles) {
+        dma(t + nx, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PASSES) : "memory");     // the first tile's pieces (issued first) landed
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int it = 0; t < n_tiles; t += nx, ++it) {
+        const int buf = it & 1;
+        if (it > 0 && t + nx < n_tiles) dma(t + nx, buf ^ 1);
+        if (active) {
+            int G = (fh ^ ((frow >> FS) & FM)) << 4;
+            const unsigned char* lb = lds + (size_t)buf * TILE_CHUNKS * 16 + frow * CPR * 16;
+#pragma unroll 1
+            for (int rq = rq_begin; rq < rq_end; ++rq) {
+                asm volatile("" : "+v"(G));
+                const unsigned char* lq = lb + rq * 32 * CPR * 16;
+                f32x16 acc[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                bf16x8 a[AHEAD];
+#pragma unroll
+                for (int s_ = 0; s_ < AHEAD; ++s_) a[s_] = *reinterpret_cast<const bf16x8*>(lq + ((32 * s_) ^ G));
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    const bf16x8 cur = a[s_ % AHEAD];
+                    if (s_ + AHEAD < KS) a[s_ % AHEAD] = *reinterpret_cast<const bf16x8*>(lq + ((32 * (s_ + AHEAD)) ^ G));
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, qf[0][s_], acc[0], 0, 0, 0);
+                    if (second) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, qf[1][s_], acc[1], 0, 0, 0);
+                }
+                const long long col0 = (((long long)t * 4 + rq) * 2 + fh) * SUB;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = q0 + j * 32 + frow;
+                    if (q >= nq) continue;
+                    float* dst = gm + (long long)q * ldm + col0;
+                    if (SUB == 16) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<f32x4*>(dst + 4 * g) = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                    } else {
+                        float m4[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {       // v > m ? v : m: a NaN score never wins (sample_threshold_kernel's rule)
+                            float m = acc[j][4 * g];
+#pragma unroll
+                            for (int e = 1; e < 4; ++e) m = acc[j][4 * g + e] > m ? acc[j][4 * g + e] : m;
+                            m4[g] = m;
+                        }
+                        if (SUB == 4) {
+                            *reinterpret_cast<f32x4*>(dst) = f32x4{m4[0], m4[1], m4[2], m4[3]};
+                        } else {
+                            float m = m4[0];
+#pragma unroll
+                            for (int g = 1; g < 4; ++g) m = m4[g] > m ? m4[g] : m;
+                            *dst = m;
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// tau[q] for every query from the group maxima: one wave per query, eight queries per workgroup
+__global__ __launch_bounds__(512) void tau_from_maxima_kernel(const float* gm, long long ldm, long long n, int r, int nq,
+                                                              float* tau) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 8 + w;
+    if (q >= nq) return;
+    const float t = wave_tau(gm + (long long)q * ldm, n, r, lane);
+    if (lane == 0) tau[q] = t;
+}
+
 // segments per query = workgroups per 512-query group of the streaming pass; each owns CAND_CAP / nseg candidate slots
 static inline int scan_segments(long long nrows, long long nq) {
     const long long ntiles = (nrows + SCAN_ROWS - 1) / SCAN_ROWS;
@@ -594,7 +814,8 @@ static inline int scan_segments(long long nrows, long long nq) {
 
 template <int KS>
 static hipError_t launch_scan(const uint16_t* X16, long long ld16, long long nrows, const uint16_t* Q16, int nq,
-                              const float* tau, unsigned long long* cand, int* segcnt, int* ocnt, hipStream_t st) {
+                              float* tau, unsigned long long* cand, int* segcnt, int* ocnt, hipStream_t st,
+                              const float* gm = nullptr, long long ldm = 0, long long gm_n = 0, int rank = 0) {
     auto kern = scan_filter_kernel<KS>;
     constexpr size_t lds_bytes = 2ull * SCAN_ROWS * 2 * KS * 16 + SCAN_HIT_BYTES + SCAN_QGROUP * 4;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
@@ -611,7 +832,59 @@ static hipError_t launch_scan(const uint16_t* X16, long long ld16, long long nro
     ProfScope prof("search_filter_stream128x512_bf16", 2.0 * (double)nrows * (double)nq * d,
                    2.0 * ((double)nrows * d * ny + (double)nq * d), st);
     hipLaunchKernelGGL(kern, dim3((unsigned)(nx * ny)), dim3(512), lds_bytes, st, X16, ld16, nrows, Q16, nq, tau, cand, segcnt,
-                       ocnt, CAND_CAP / nx, nx);
+                       ocnt, CAND_CAP / nx, nx, gm, ldm, gm_n, rank);
+    return hipGetLastError();
+}
+
+// the fused conversion + sample launch: n_tiles evenly spaced 128-row tiles -> gm[nq][ldm], ldm = columns = n_tiles * 8 * SUB
+struct SamplePlan {
+    int n_tiles, tstride, sub;
+    long long cols;
+};
+static inline SamplePlan sample_plan(long long nrows, long long n_sample_rows) {
+    SamplePlan sp;
+    const long long full = nrows / SCAN_ROWS;                          // whole tiles only
+    long long nt = (n_sample_rows + SCAN_ROWS - 1) / SCAN_ROWS;
+    if (nt > full) nt = full;
+    if (nt < 1) nt = 1;
+    sp.n_tiles = (int)nt;
+    sp.tstride = (int)(full / nt);
+    const long long rows = nt * SCAN_ROWS;
+    sp.sub = rows / 16 >= 1024 ? 1 : (rows / 4 >= 1024 ? 4 : 16);      // keep >= ~1000 columns where the sample allows
+    sp.cols = nt * 8 * sp.sub;
+    return sp;
+}
+template <int KS>
+static hipError_t launch_sample(const uint16_t* X16, long long ld16, const SamplePlan& sp, const float* Q, long long ldq,
+                                int nq, uint16_t* Q16, float* gm, int* zero, long long n_zero, hipStream_t st) {
+    constexpr size_t lds_bytes = 2ull * SCAN_ROWS * 2 * KS * 16;
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_max_kernel<KS, 1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_max_kernel<KS, 4>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_max_kernel<KS, 16>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done.mark();
+    }
+    const int ny = (nq + SCAN_QGROUP - 1) / SCAN_QGROUP;
+    int nx = 256 / ny;
+    nx = nx < 1 ? 1 : (nx > sp.n_tiles ? sp.n_tiles : nx);
+    const int d = 16 * KS;
+    ProfScope prof("search_sample_max128x512_bf16", 2.0 * (double)sp.n_tiles * SCAN_ROWS * (double)nq * d,
+                   2.0 * (double)sp.n_tiles * SCAN_ROWS * d * ny + 4.0 * (double)nq * d + 4.0 * (double)nq * sp.cols, st);
+    const dim3 grid((unsigned)(nx * ny)), block(512);
+    if (sp.sub == 1)
+        hipLaunchKernelGGL((sample_max_kernel<KS, 1>), grid, block, lds_bytes, st, X16, ld16, sp.tstride, sp.n_tiles, Q, ldq, nq,
+                           Q16, gm, sp.cols, nx, zero, n_zero);
+    else if (sp.sub == 4)
+        hipLaunchKernelGGL((sample_max_kernel<KS, 4>), grid, block, lds_bytes, st, X16, ld16, sp.tstride, sp.n_tiles, Q, ldq, nq,
+                           Q16, gm, sp.cols, nx, zero, n_zero);
+    else
+        hipLaunchKernelGGL((sample_max_kernel<KS, 16>), grid, block, lds_bytes, st, X16, ld16, sp.tstride, sp.n_tiles, Q, ldq, nq,
+                           Q16, gm, sp.cols, nx, zero, n_zero);
     return hipGetLastError();
 }
 
@@ -948,7 +1221,7 @@ struct SearchPlan {
     long long gstride;       // rows between sample blocks
     int rank;                // r
     int nslices;             // fix-up slices
-    size_t off_tau, off_cnt, off_ocnt, off_fail, off_segcnt, off_cand, off_sample, off_fix, off_q16, off_m, off_eps, bytes;
+    size_t off_tau, off_cnt, off_ocnt, off_ticket, off_fail, off_segcnt, off_cand, off_sample, off_fix, off_q16, off_m, off_eps, bytes;
 };
 
 // dim16 > 0: the mixed-precision search, which also keeps a bf16 copy of the queries in the workspace
@@ -975,8 +1248,9 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
     pl.nslices = ns < 1 ? 1 : (ns > 16 ? 16 : ns);
     size_t o = 0;
     pl.off_tau = o;    o = align_up(o + (size_t)nq * 4, 256);
-    pl.off_cnt = o;    o = align_up(o + (size_t)nq * 4, 256);                   // cnt | ocnt | fail: one memset
+    pl.off_cnt = o;    o = align_up(o + (size_t)nq * 4, 256);                   // cnt | ocnt | ticket | fail: cleared together
     pl.off_ocnt = o;   o = align_up(o + (size_t)nq * 4, 256);
+    pl.off_ticket = o; o = align_up(o + (size_t)nq * 4, 256);                   // fix-up: slices finished per query
     pl.off_fail = o;   o = align_up(o + (size_t)(nq + 1) * 4, 256);
     pl.off_segcnt = o; o = align_up(o + (size_t)(dim16 ? nq : 0) * 256 * 4, 256);  // streaming pass: hits per (query, segment)
     pl.off_cand = o;   o = align_up(o + (size_t)nq * CAND_CAP * 8 * (dim16 ? 2 : 1), 256);   // mixed: + overflow block
@@ -1107,7 +1381,7 @@ extern "C" int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld
     if (attr_done.pending()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_merge_kernel),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
         attr_done.mark();
     }
@@ -1115,11 +1389,10 @@ extern "C" int amdrec_flat_search(const float* corpus, int64_t nrows, int64_t ld
     unsigned long long* fix = reinterpret_cast<unsigned long long*>(ws + pl.off_fix);
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st, cand, cnt, CAND_CAP, k,
                        (long long)nrows, fail, out_scores, (long long*)out_pos, (long long)pos_offset);
-    hipLaunchKernelGGL(fixup_scan_kernel, dim3((unsigned)(pl.nslices * (nq < FIX_GRID_Q ? nq : FIX_GRID_Q))), dim3(512), 0, st, corpus,
-                       (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, (int)nq, k,
-                       pl.nslices, fix);
-    hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)(nq < FIX_GRID_Q ? nq : FIX_GRID_Q)), dim3(512), CAND_CAP * 8, st, fix, fail, (int)nq, k,
-                       pl.nslices, out_scores, (long long*)out_pos, (long long)pos_offset);
+    hipLaunchKernelGGL(fixup_kernel, dim3((unsigned)(pl.nslices * (nq < FIX_GRID_Q ? nq : FIX_GRID_Q))), dim3(512), CAND_CAP * 8, st,
+                       corpus, (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, (int)nq, k,
+                       pl.nslices, fix, reinterpret_cast<int*>(ws + pl.off_ticket), out_scores, (long long*)out_pos,
+                       (long long)pos_offset);
     HIP_TRY(hipGetLastError());
     if (n_fixup) HIP_TRY(hipMemcpyAsync(n_fixup, fail + nq, sizeof(int), hipMemcpyDeviceToDevice, st));
     return AMDREC_OK;
@@ -1189,7 +1462,36 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     const int seg_cap = CAND_CAP / nseg;
     const int* segcnt = streaming ? reinterpret_cast<int*>(ws + pl.off_segcnt) : cnt;
 
-    if (nrows > 0) {
+    if (streaming && pl.n_sample > 0) {
+        // conversion + sample in ONE launch (group maxima only), tau from the maxima: inside the corpus pass for <= 8
+        // queries (no threshold launch), one wave per query otherwise
+        uint16_t* q16 = reinterpret_cast<uint16_t*>(ws + pl.off_q16);
+        float* gm = reinterpret_cast<float*>(ws + pl.off_sample);
+        float* tau_ = reinterpret_cast<float*>(ws + pl.off_tau);
+        unsigned long long* cand_ = reinterpret_cast<unsigned long long*>(ws + pl.off_cand);
+        int* sc_ = reinterpret_cast<int*>(ws + pl.off_segcnt);
+        const SamplePlan sp = sample_plan(nrows, pl.n_sample);
+        REQUIRE(sp.cols <= pl.n_sample, "internal: sample maxima do not fit their workspace");
+        const bool tau_in_scan = nq <= 8;
+        hipError_t e;
+        auto run = [&](auto ks_tag) -> hipError_t {
+            constexpr int KS = decltype(ks_tag)::value;
+            hipError_t e2 = launch_sample<KS>(corpus_bf16, ld_bf16, sp, queries, ld_queries, (int)nq, q16, gm, cnt, n_zero, st);
+            if (e2 != hipSuccess) return e2;
+            if (!tau_in_scan) {
+                ProfScope prof("search_threshold", 0.0, 4.0 * (double)nq * (double)sp.cols, st);
+                hipLaunchKernelGGL(tau_from_maxima_kernel, dim3((unsigned)((nq + 7) / 8)), dim3(512), 0, st, (const float*)gm,
+                                   sp.cols, sp.cols, pl.rank, (int)nq, tau_);
+            }
+            return launch_scan<KS>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, sc_, ocnt, st,
+                                   tau_in_scan ? (const float*)gm : nullptr, sp.cols, sp.cols, pl.rank);
+        };
+        if (dim == 256)      e = run(std::integral_constant<int, 16>{});
+        else if (dim == 128) e = run(std::integral_constant<int, 8>{});
+        else if (dim == 64)  e = run(std::integral_constant<int, 4>{});
+        else                 e = run(std::integral_constant<int, 2>{});
+        HIP_TRY(e);
+    } else if (nrows > 0) {
         uint16_t* q16 = reinterpret_cast<uint16_t*>(ws + pl.off_q16);
         hipLaunchKernelGGL(bf16_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, queries, (long long)nq,
                            (long long)ld_queries, dim, q16, (long long)dim, (float*)nullptr, cnt, n_zero);
@@ -1204,7 +1506,7 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
         else               e = run_passes<Shape<4, 1, 2, 1, false, true>>(X, ldx, nrows, dh, Q, ldq, (int)nq, pl, ws, st, dim, !streaming, CSTRIDE);
         HIP_TRY(e);
         if (streaming) {
-            const float* tau_ = reinterpret_cast<const float*>(ws + pl.off_tau);
+            float* tau_ = reinterpret_cast<float*>(ws + pl.off_tau);
             unsigned long long* cand_ = reinterpret_cast<unsigned long long*>(ws + pl.off_cand);
             int* sc_ = reinterpret_cast<int*>(ws + pl.off_segcnt);
             if (dim == 256)      e = launch_scan<16>(corpus_bf16, ld_bf16, nrows, q16, (int)nq, tau_, cand_, sc_, ocnt, st);
@@ -1223,7 +1525,7 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_sort_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_merge_kernel),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
         attr_done.mark();
     }
@@ -1256,11 +1558,10 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
         }
     }
     ProfScope prof_fix("search_fixup", 0.0, 0.0, st);
-    hipLaunchKernelGGL(fixup_scan_kernel, dim3((unsigned)(pl.nslices * (nq < FIX_GRID_Q ? nq : FIX_GRID_Q))), dim3(512), 0, st, corpus,
-                       (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, (int)nq, k,
-                       pl.nslices, fix);
-    hipLaunchKernelGGL(fixup_merge_kernel, dim3((unsigned)(nq < FIX_GRID_Q ? nq : FIX_GRID_Q)), dim3(512), CAND_CAP * 8, st, fix, fail, (int)nq, k,
-                       pl.nslices, out_scores, (long long*)out_pos, (long long)pos_offset);
+    hipLaunchKernelGGL(fixup_kernel, dim3((unsigned)(pl.nslices * (nq < FIX_GRID_Q ? nq : FIX_GRID_Q))), dim3(512), CAND_CAP * 8, st,
+                       corpus, (long long)ld_corpus, (long long)nrows, dim, queries, (long long)ld_queries, fail, (int)nq, k,
+                       pl.nslices, fix, reinterpret_cast<int*>(ws + pl.off_ticket), out_scores, (long long*)out_pos,
+                       (long long)pos_offset);
     HIP_TRY(hipGetLastError());
     if (n_fixup) HIP_TRY(hipMemcpyAsync(n_fixup, fail + nq, sizeof(int), hipMemcpyDeviceToDevice, st));
     return AMDREC_OK;
