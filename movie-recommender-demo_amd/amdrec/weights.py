@@ -171,6 +171,18 @@ def x3b_stream_gemm256(fr):
     return np.stack(out)
 
 
+def x3b_stream_cross(fr):
+    """A cross layer's 256 x 256 GEMM in four QUARTERS of the output features (4 tiles of 16 = 2 tile pairs each, 16 groups =
+    4 chunks): the 16-row kernel keeps x0 in registers across the cross layers and can only afford a 16-register
+    accumulator beside it (csrc/rowowner16_impl.hpp phase_cross).  Within a quarter: k-step major, as in gemm256."""
+    out = []
+    for q4 in range(fr.shape[0] // 4):
+        for ks in range(fr.shape[1]):
+            for pr in range(2):
+                out += _pair(fr, 2 * (2 * q4 + pr), ks)
+    return np.stack(out)
+
+
 def x3b_stream_ffn(f1, f2):
     T = f1.shape[0] // 2                     # hidden tiles of 32
     out = []
@@ -201,6 +213,7 @@ def pack_x3_stream(mats: Dict, variant: int = 32) -> Dict:
     assert variant in (16, 32)
     frags, s_gemm, s_ffn, s_heads = ((x3_frags, x3_stream_gemm256, x3_stream_ffn, x3_stream_heads) if variant == 32 else
                                      (x3b_frags, x3b_stream_gemm256, x3b_stream_ffn, x3b_stream_heads))
+    s_cross = s_gemm if variant == 32 else x3b_stream_cross
     parts = []
     sc = {"sw_ov": [], "sw_1": [], "sw_2": [], "hn": [], "hb": [], "sw_cross": []}
     for l in range(len(mats["ov"])):
@@ -214,7 +227,7 @@ def pack_x3_stream(mats: Dict, variant: int = 32) -> Dict:
         sc["hb"].append(float(np.abs(mats["b1"][l]).max()))
     for w in mats["cross"]:
         s = x3_pow2_scale(np.abs(w).max())
-        parts.append(s_gemm(frags(w, s)))
+        parts.append(s_cross(frags(w, s)))
         sc["sw_cross"].append(s)
     sh1 = x3_pow2_scale(np.abs(mats["h1"]).max())
     sh2 = x3_pow2_scale(max(np.abs(w).max() for w in mats["h2"]))

@@ -532,21 +532,48 @@ __device__ __forceinline__ void store_rows(const f32x4 (&x)[16], float* row_ptr,
     for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(row_ptr + 16 * t + 4 * g) = x[t];
 }
 
+// one QUARTER of a cross layer's 256 x 256 GEMM: output tiles 4 Q4 .. 4 Q4 + 3 (two tile pairs), 16 groups = 4 chunks,
+// k-step major (amdrec/weights.py x3b_stream_cross); `cur` holds group I's fragments
+template <class RingX, int I>
+__device__ __forceinline__ void cross_quarter_groups(RingX& ring, f16x8 (&cur)[4], const f16x8 (&xh)[8], const f16x8 (&xl)[8],
+                                                     f32x4 (&acc)[4]) {
+    constexpr int ks = I >> 1, pr = I & 1;
+    f16x8 nxt[4];
+    if constexpr (I < 15) ring.template read4<(I + 1) & 7>(nxt);
+    ring.timed_landed(cur);
+    group6(cur, xh[ks], xl[ks], acc[2 * pr], acc[2 * pr + 1]);
+    if constexpr (I < 15) cross_quarter_groups<RingX, I + 1>(ring, nxt, xh, xl, acc);
+}
+
+// xl <- x0 * (xl W + b) + xl with x0 IN REGISTERS (round 2 wrote the trunk's output to HBM once and read it back in each of
+// the three cross layers: 1.05 of the launch's 1.99 GB of HBM traffic).  x0 (64 registers) + the residual xl (64) + the
+// planes of xl (64) leave room for a 16-register accumulator, so the GEMM runs in four quarters of the output features;
+// a quarter's epilogue updates its own four tiles of xl in place - the planes were taken from the old xl, and a tile's
+// residual is its own old value.  Same MFMAs in the same order per output element as the undivided GEMM: bit-identical.
 template <class RingX>
-__device__ __forceinline__ void phase_cross(RingX& ring, const Phase& P, f32x4 (&xl_)[16], const float* x0_row, int g,
-                                            lds_cfloat* pb) {
+__device__ __forceinline__ void phase_cross(RingX& ring, const Phase& P, f32x4 (&xl_)[16], const f32x4 (&x0)[16], lds_cfloat* pb) {
     float s, inv;
     row_scale(xl_, s, inv);
     f16x8 xh[8], xl[8];
-    f32x4 acc[16];
-    prepare<false>(xl_, s, pb, P.b1, s * P.sw1, xh, xl, acc);
-    gemm256(ring, xh, xl, acc);
-    const float un = inv / P.sw1;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x0_row + 16 * t + 4 * g);
+    for (int ks = 0; ks < 8; ++ks) split8(xl_[2 * ks], xl_[2 * ks + 1], s, xh[ks], xl[ks]);
+    const float bs = s * P.sw1, un = inv / P.sw1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xl_[t][r] = v0[r] * (acc[t][r] * un) + xl_[t][r];
+    for (int q4 = 0; q4 < 4; ++q4) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 b = param4(pb, P.b1, 4 * q4 + i);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][r] = b[r] * bs;
+        }
+        f16x8 cur[4];
+        ring.template read4<0>(cur);
+        cross_quarter_groups<RingX, 0>(ring, cur, xh, xl, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xl_[4 * q4 + i][r] = x0[4 * q4 + i][r] * (acc[i][r] * un) + xl_[4 * q4 + i][r];
     }
 }
 
@@ -622,25 +649,24 @@ __device__ __forceinline__ void run_chain(const Program& G, const Input& in, lon
         load_rows(x, in.cache + a * in.ldc, g);
         add_rows(x, in.U + (gr / in.rowdiv) * 256, g);
     }
-    float* x0_row = scratch + row * 256;
-    bool x0_saved = false;
-    for (int p = 0; p < G.n_phases; ++p) {
+    // The chain is [encoder phases] [cross phases] [heads] (ranker_x3.hip x3_build), walked as three loops so that x0 - the
+    // trunk's output, 64 registers - is live only across the cross layers.
+    int p = 0;
+    for (; p < G.n_phases; ++p) {
         const Phase& P = G.ph[p];
         const int type = __builtin_amdgcn_readfirstlane(P.type);
-        if (type == x3::PH_ATTN_LN) {
-            phase_attn_ln(ring, P, x, pb);
-        } else if (type == x3::PH_FFN_LN) {
-            phase_ffn_ln(ring, P, x, pb);
-        } else if (type == x3::PH_CROSS) {
-            if (!x0_saved) {
-                store_rows(x, x0_row, g);
-                x0_saved = true;
-            }
-            phase_cross(ring, P, x, x0_row, g, pb);
-        } else {
-            phase_heads(ring, G, P, x, logits, ld_logits, row, row_ok, g, pb);
-        }
+        if (type == x3::PH_ATTN_LN) phase_attn_ln(ring, P, x, pb);
+        else if (type == x3::PH_FFN_LN) phase_ffn_ln(ring, P, x, pb);
+        else break;
     }
+    if (p < G.n_phases && __builtin_amdgcn_readfirstlane(G.ph[p].type) == x3::PH_CROSS) {
+        f32x4 x0[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) x0[t] = x[t];
+        for (; p < G.n_phases && __builtin_amdgcn_readfirstlane(G.ph[p].type) == x3::PH_CROSS; ++p)
+            phase_cross(ring, G.ph[p], x, x0, pb);
+    }
+    if (p < G.n_phases) phase_heads(ring, G, G.ph[p], x, logits, ld_logits, row, row_ok, g, pb);
     if (x_out != nullptr && row_ok) store_rows(x, x_out + row * ld_xout, g);
     ring.drain();
     if ((DBG & 16) && lane == 0) {            // diagnostic build: cycle stamps into the unused tail of the logits buffer
@@ -652,7 +678,8 @@ __device__ __forceinline__ void run_chain(const Program& G, const Input& in, lon
     }
 }
 
-__global__ __launch_bounds__(64 * WAVES, 2) void ranker_x3b_kernel(Program G, Input in, long long rows, float* scratch,
+// (second bound = waves per SIMD: the 4-wave shape has a SIMD - and its 512 registers - to itself)
+__global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 2 : 1) void ranker_x3b_kernel(Program G, Input in, long long rows, float* scratch,
                                                             float* x_out, long long ld_xout, float* logits,
                                                             long long ld_logits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -238,9 +238,18 @@ def test_16_row_variant_stream_order_and_k_permutation():
         got = rows(acc2) / p.x3.sw_2[l]
         ref = np.maximum(x @ w1.T + b1, 0) @ w2.T
         assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), ("ffn", l)
+    def gemm256_quarters():                 # the cross layers' order: four quarters of the output tiles, k-step major inside
+        acc = [np.zeros((16, 16), F) for _ in range(16)]
+        xb = _b16(x)
+        for q4 in range(4):
+            for ks in range(8):
+                for pr in range(2):
+                    _group(st, xb[ks], acc, 2 * (2 * q4 + pr))
+        return rows(acc)
+
     for c in range(3):
         wc = f64(f"feature_interaction.cross_weights.{c}")
-        got = gemm256() / p.x3.sw_cross[c]
+        got = gemm256_quarters() / p.x3.sw_cross[c]
         assert np.abs(got - x @ wc).max() <= 1e-5 * np.abs(x @ wc).max(), ("cross", c)
     xb = _b16(x)
     for t in tasks:

@@ -33,8 +33,16 @@ def short(name):
         return f"{epi}_256x128_x6"
     if "scan_filter_kernel" in name:
         return "search_filter_stream128x512_bf16"
+    if "x3b4::ranker_x3b_kernel" in name:
+        return "ranker_rowowner16_64_x3"
     if "ranker_x3b_kernel" in name:
         return "ranker_rowowner16_128_x3"
+    if "sample_max_kernel" in name:
+        return "search_sample_max128x512_bf16"
+    if "tau_from_maxima_kernel" in name:
+        return "search_threshold"
+    if "fixup_kernel" in name:
+        return "search_fixup"
     if "ranker_x3_kernel" in name:
         return "ranker_rowowner_128_x3"
     if "finalize_mixed_kernel" in name:
