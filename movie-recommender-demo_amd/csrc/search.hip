@@ -610,6 +610,9 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
         for (int h = lane; h < npend; h += 64)
             append(reinterpret_cast<const int*>(lprev + SCAN_WHITS * 8)[h],
                    reinterpret_cast<const unsigned long long*>(lprev)[h]);
+        // (the DMA goes out right after the barrier: issuing it behind the first quarter's MFMAs, the move that gained 4 % in
+        // the row-owner kernel, cost 30 % here - 0.355 against 0.268 ms at 512 queries, profiles/r03_scan_late_dma_ab.log: with a
+        // two-deep ring the next tile needs the whole of this tile's compute time to land)
         if (t + nx < ntiles) dma(t + nx, buf ^ 1);
         int wcount = 0;
         if (active) {
