@@ -70,7 +70,8 @@ int main(int argc, char** argv) {
     H.type = x3::PH_HEADS; H.n_steps = h1 / 32; H.n_tasks = T; H.b1 = 0; H.sw1 = sw; H.sw2 = sw; H.hn = 8.f; H.hb = 0.01f;
     for (int t = 0; t < T; ++t) { G.hb2[t] = 0; G.hw3[t] = 64; G.hb3[t] = 128; }
     G.params = dpar; G.n_params = PROBE_PARAM_FLOATS;
-    G.n_phases = n; G.total_chunks = (int)chunks; G.stream = (const unsigned char*)dstream;
+    G.n_phases = n - (argc > 3 ? atoi(argv[3]) : 0);   // argv[3]: drop the last phases (time of a prefix of the chain)
+    G.total_chunks = (int)chunks; G.stream = (const unsigned char*)dstream;
     x3::Input in{};
     in.X = dX; in.ldx = 256;
     CK(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + PROBE_PARAM_FLOATS * 4));
