@@ -76,6 +76,7 @@ class IVFState:
         self.device = centroids.device
         self.assign = torch.empty(0, dtype=torch.int64, device=self.device)   # list of every position
         self._lists = None                                          # (xs, spos, list_off, list_len, max_len)
+        self._top_rows = None                                       # host: rows of the p longest lists (pool_rows_bound)
 
     # -- build ----------------------------------------------------------------------------
     @classmethod
@@ -107,6 +108,7 @@ class IVFState:
         assert start == self.assign.shape[0]
         self.assign = torch.cat([self.assign, _assign(x_normalised, self.centroids)])
         self._lists = None
+        self._top_rows = None
 
     def _build_lists(self, xb: torch.Tensor, n: int):
         if self._lists is None or self._lists[5] != n:
@@ -117,7 +119,18 @@ class IVFState:
             off[1:] = torch.cumsum(counts, 0)
             xs = xb[:n][order].contiguous()
             self._lists = (xs, order.contiguous(), off, counts.to(torch.int64), int(counts.max().item()) if n else 0, n)
+            # rows of the p longest lists, p = 1 .. nlist: the tight host-side bound of a query's candidate pool
+            # (its nprobe probed lists cannot hold more than the nprobe longest; once per list rebuild, like max above)
+            self._top_rows = np.cumsum(np.sort(counts.cpu().numpy())[::-1].astype(np.int64))
         return self._lists
+
+    def pool_rows_bound(self, nprobe: int) -> int:
+        """Upper bound of the rows a query's ``nprobe`` probed lists hold = the ``nprobe`` longest lists' rows.  Round 2
+        sized the pool as nprobe x the longest list (9767 x 64 keys = 5 MB per query at 10M / 4096: 512 queries needed two
+        chunks of the 2 GB pool); list lengths spread 0 .. 4x the mean, so this is ~1.6x tighter."""
+        if self._top_rows is None or len(self._top_rows) == 0:
+            return 1
+        return max(1, int(self._top_rows[min(int(nprobe), len(self._top_rows)) - 1]))
 
     # -- search ---------------------------------------------------------------------------
     def search(self, xb: torch.Tensor, n: int, q: torch.Tensor, k: int, nprobe: int, out_scores: torch.Tensor,
@@ -140,7 +153,7 @@ class IVFState:
         # 2. pool layout + (query, probe) pairs grouped by list: amdrec_ivf_group (kernels, no host sync)
         base = torch.empty((nq, nprobe), dtype=torch.int64, device=self.device)
         n_pool = torch.empty((nq,), dtype=torch.int64, device=self.device)
-        pool_ld = max(1, nprobe * max_len)
+        pool_ld = self.pool_rows_bound(nprobe)
         chunk = max(1, min(nq, 65535, POOL_BYTES // (pool_ld * 8)))
         grouped = nq >= GROUPED_MIN_QUERIES
         qtile = QTILE_SPARSE if min(chunk, nq) * nprobe < SPARSE_PAIRS_PER_LIST * self.nlist else QTILE
