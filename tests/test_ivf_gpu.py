@@ -204,3 +204,44 @@ def test_ivf_select_boundary_ties(copies):
         assert 0 < len(ref_t) < copies                          # the copies do straddle the boundary
         assert got_t == ref_t == sorted(ref_t)                  # the tied rows that made it: the lowest positions, in order
     oracle.search.check_topk(rD, rI, D, ids, tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
+
+
+@pytest.mark.parametrize("n,nlist,k,copies", [(6_000, 64, 900, 3),       # phase-1 pool (2 lists) smaller than k for some queries
+                                              (40_000, 64, 300, 4)])     # phase-1 pool larger than k for most queries: tau is a real score
+def test_two_phase_grouped_scan_with_ties_at_tau(n, nlist, k, copies):
+    """the exact two-phase scan (>= 16 queries take the grouped scan, >= 16 probes split it: the nearest eighth
+    of the probes unfiltered -> tau = that subset's k-th score -> the other probes keep rows with score >= tau) on a corpus
+    of duplicated rows: every row `copies` times, so rows tie AT tau and across the two phases; with the small corpus the
+    first phase's pool is smaller than k (tau = -inf: the filter must keep everything).  Result == the oracle's given the
+    same probes: tolerance-aware on scores, and the tied rows that made the cut are the lowest positions."""
+    from amdrec.index import FAISSIndex, flat_search
+    from amdrec import ivf
+    nq, nprobe = 24, 16
+    assert nq >= ivf.GROUPED_MIN_QUERIES and nprobe >= ivf.TWO_PHASE_MIN_PROBES
+    base = _clustered(n // copies, 256, 12, 21)
+    xb = np.concatenate([base] * copies)                        # copy j of row i at position j * (n // copies) + i
+    xq = _clustered(nq, 256, 12, 22)
+    idx = FAISSIndex(256, index_type="IVF", nlist=nlist, nprobe=nprobe)
+    idx.add(xb)
+    ids, D = idx.search(xq, k)
+    xbn, xqn = oracle.search.normalize_l2(xb), oracle.search.normalize_l2(xq)
+    cs = torch.empty((nq, nprobe), dtype=torch.float32, device="cuda")
+    pr = torch.empty((nq, nprobe), dtype=torch.int64, device="cuda")
+    flat_search(idx._ivf.centroids, nlist, torch.from_numpy(xqn).cuda(), nprobe, cs, pr)
+    rD, rI = oracle.search.ivf_search(xbn, idx._ivf.assign.cpu().numpy(), idx._ivf.centroids.cpu().numpy(), xqn, k, nprobe,
+                                      probes=pr.cpu().numpy())
+    oracle.search.check_topk(rD, rI, D, ids, tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
+    m = n // copies
+    for q in range(nq):
+        valid = ids[q][ids[q] >= 0]
+        assert len(set(valid.tolist())) == len(valid)           # a row filed in one phase is not appended again by the other
+        # identical copies carry bit-identical scores: among the copies of one base row the lower positions come first
+        for i in set((valid % m).tolist()):
+            got = [int(p) for p in valid if p % m == i]
+            assert got == sorted(got)
+    lens = torch.bincount(idx._ivf.assign, minlength=nlist)
+    pool1 = lens[pr[:, :max(2, nprobe // 8)]].sum(1)           # rows of every query's first-phase probes
+    if n == 6_000:
+        assert bool((pool1 < k).any())                          # tau = -inf for those queries: the filter keeps everything
+    else:
+        assert bool((pool1 >= k).any())                         # tau is a real score there, with copies tying at it
