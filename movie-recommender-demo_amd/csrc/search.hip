@@ -1230,9 +1230,24 @@ struct SearchPlan {
 // dim16 > 0: the mixed-precision search, which also keeps a bf16 copy of the queries in the workspace
 static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int dim16 = 0) {
     long long nt = (nrows + SAMPLE_G - 1) / SAMPLE_G;
-    // expected candidates per query: far enough above k that an unlucky sample cannot undershoot it (the
-    // estimate's sigma is ~target/8), small enough that the finalize sort stays at 2048 keys for k = 500
-    long long target = (2ll * k > k + 900ll) ? 2ll * k : k + 900ll;
+    // expected candidates per query: far enough above k that an unlucky sample cannot undershoot it (the estimate's
+    // sigma is ~target/8: k = 500 -> 1400 = k + 5.1 sigma), small enough that the finalize sort stays at 2048 keys for
+    // k = 500.  Round 2 gave every k at least k + 900 - for the SHORT per-shard lists of the sharded search (128 of 500 at 8
+    // ranks) that is 7 sigma and, on a shard an eighth the size, 8x the hit density of the single-GPU pass.  Now, for
+    // batches whose corpus pass is compute-side bound (>= 256 queries; a small batch is HBM-bound and pays more for a larger
+    // sample than its candidates cost): between the 5.1-sigma floor max(2.8 k, k + 256) and k + 900, the value that balances
+    // the sample (rows ~ 64 nrows / target) against the per-hit work of the pass (~ target): ~0.6 sqrt(nrows), fitted to
+    // same-box runs at 125k-row shards and 1M rows (profiles/r03_shard_search_target.log: per-rank search at the 8-rank
+    // shape 0.766 -> 0.660 ms, k = 500 at 1M unchanged).
+    long long t5 = k + 900ll;
+    if (nq >= 256) {
+        long long lo = (28ll * k + 9) / 10;
+        if (lo < k + 256ll) lo = k + 256ll;
+        long long opt = (long long)(0.6 * sqrt((double)(nrows > 0 ? nrows : 1)));
+        if (opt < lo) opt = lo;
+        if (opt < t5) t5 = opt;
+    }
+    long long target = (2ll * k > t5) ? 2ll * k : t5;
     if (nrows <= CAND_CAP) {
         pl.n_sample = 0;                  // every row becomes a candidate
         pl.gstride = SAMPLE_G;
