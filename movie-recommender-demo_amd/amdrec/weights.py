@@ -196,13 +196,18 @@ def x3b_stream_ffn(f1, f2):
 
 
 def x3b_stream_heads(f1, f2s, tiles_per_task):
+    """Heads of the 16-row kernel, software-pipelined like the FFN (csrc/rowowner16_impl.hpp heads_step): step tt = the 8
+    stage-1 groups of hidden tile tt (tiles counted through all tasks) with the 2 stage-2 groups of tile tt - 1 behind
+    u = 3 and u = 7; step 0 has no stage 2, the last step no stage 1."""
+    nt = len(f2s) * tiles_per_task
     out = []
-    for task, f2 in enumerate(f2s):
-        for t in range(tiles_per_task):
-            for u in range(8):
-                out += _pair(f1, 2 * (task * tiles_per_task + t), u)
-            for pr in range(2):
-                out += _pair(f2, 2 * pr, t)
+    for tt in range(nt + 1):
+        prev = tt - 1
+        for u in range(8):
+            if tt < nt:
+                out += _pair(f1, 2 * tt, u)
+            if tt >= 1 and u in (3, 7):
+                out += _pair(f2s[prev // tiles_per_task], 2 * (u // 4), prev % tiles_per_task)
     return np.stack(out)
 
 

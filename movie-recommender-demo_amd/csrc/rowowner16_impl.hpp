@@ -577,6 +577,36 @@ __device__ __forceinline__ void phase_cross(RingX& ring, const Phase& P, f32x4 (
     }
 }
 
+// One step of the heads, software-pipelined like the FFN (round 3; the heads used to finish a hidden tile's stage 1, convert
+// it and only then run its stage 2: a dependency bubble per tile and two fragment reads with nothing to hide behind - 5.45 us
+// per chunk against the FFN's 4.55): the stage-1 groups of hidden tile tt (8: W_1 tiles 2tt, 2tt+1 at ks = u) with the two
+// stage-2 groups of tile tt - 1 (W_2 tile pairs 0 and 1 of that tile's task, at k-step = its index in the task) riding behind
+// u = 3 and u = 7.  Stream order: amdrec/weights.py x3b_stream_heads.  P0 = position of the step's first group in its
+// chunk (0 or 2: a full step is 10 groups = 2.5 chunks).
+template <class RingX, bool S1, bool S2, int P0, int GI>
+__device__ __forceinline__ void heads_groups(RingX& ring, f16x8 (&cur)[4], const f16x8 (&xh)[8], const f16x8 (&xl)[8],
+                                             f32x4& a10, f32x4& a11, f32x4 (&acc2)[4], const f16x8& hh, const f16x8& hl) {
+    static_assert(!(OPT & 128), "the heads' chunk positions are tracked modulo one chunk");
+    constexpr int NG = (S1 ? 8 : 0) + (S2 ? 2 : 0);
+    // (S1 && S2): u0 u1 u2 u3 p0 u4 u5 u6 u7 p1
+    constexpr bool is2 = S2 && (!S1 || GI == 4 || GI == 9);
+    constexpr int u = !S1 ? 0 : (S2 ? (GI < 4 ? GI : GI - 1) : GI);
+    constexpr int pr = !S1 ? GI : (GI == 9 ? 1 : 0);
+    f16x8 nxt[4];
+    if constexpr (GI < NG - 1) ring.template read4<(P0 + GI + 1) & 3>(nxt);
+    ring.timed_landed(cur);
+    if constexpr (is2) group6(cur, hh, hl, acc2[2 * pr], acc2[2 * pr + 1]);
+    else group6(cur, xh[u], xl[u], a10, a11);
+    if constexpr (GI < NG - 1) heads_groups<RingX, S1, S2, P0, GI + 1>(ring, nxt, xh, xl, a10, a11, acc2, hh, hl);
+}
+template <class RingX, bool S1, bool S2, int P0>
+__device__ __forceinline__ void heads_step(RingX& ring, const f16x8 (&xh)[8], const f16x8 (&xl)[8], f32x4& a10, f32x4& a11,
+                                           f32x4 (&acc2)[4], const f16x8& hh, const f16x8& hl) {
+    f16x8 cur[4];
+    ring.template read4<P0>(cur);
+    heads_groups<RingX, S1, S2, P0, 0>(ring, cur, xh, xl, a10, a11, acc2, hh, hl);
+}
+
 template <class RingX>
 __device__ __forceinline__ void phase_heads(RingX& ring, const Program& G, const Phase& P, const f32x4 (&x)[16], float* out,
                                             long long ld_out, long long row, bool row_ok, int g, lds_cfloat* pb) {
@@ -587,42 +617,39 @@ __device__ __forceinline__ void phase_heads(RingX& ring, const Program& G, const
     for (int ks = 0; ks < 8; ++ks) split8(x[2 * ks], x[2 * ks + 1], s, xh[ks], xl[ks]);
     const float sh = x3::hidden_scale(fmaf(P.hn * 8192.0f, inv, P.hb));
     const float b1s = s * P.sw1, c1 = sh * inv / P.sw1, un2 = 1.0f / (P.sw2 * sh), lim1 = 60000.f / c1;
-    ring.align();                                             // the phase starts on a chunk boundary
-    for (int task = 0; task < P.n_tasks; ++task) {
-        f32x4 acc2[4];
-        init_pair(acc2[0], acc2[1], pb, G.hb2[task], 0, P.sw2 * sh);
-        init_pair(acc2[2], acc2[3], pb, G.hb2[task], 2, P.sw2 * sh);
-        for (int t = 0; t < P.n_steps; ++t) {
-            f32x4 a10, a11;
-            init_pair(a10, a11, pb, P.b1 + task * P.n_steps * 32, 2 * t, b1s);
-            f16x8 cur[4], nxt[4];
-            f16x8 hh, hl;
-            ring.read4_dyn(cur);
+    const int T = P.n_steps, NT = P.n_tasks * T;               // hidden tiles per task / in all (NT even: x3_build)
+    f32x4 acc2[4], a10, a11;
+    f16x8 hh, hl;
+    init_pair(acc2[0], acc2[1], pb, G.hb2[0], 0, P.sw2 * sh);
+    init_pair(acc2[2], acc2[3], pb, G.hb2[0], 2, P.sw2 * sh);
+    init_pair(a10, a11, pb, P.b1, 0, b1s);
+    heads_step<RingX, true, false, 0>(ring, xh, xl, a10, a11, acc2, hh, hl);                   // tile 0: stage 1 only
+    int task = 0, t_in = 0;                                    // task / index of the tile whose stage 2 runs in step tt
+    for (int tt = 1; tt <= NT; ++tt) {
+        hidden_planes(a10, a11, c1, lim1, hh, hl);             // tile tt - 1
+        if (tt < NT) {
+            init_pair(a10, a11, pb, P.b1, 2 * tt, b1s);        // stacked b_1: tile tt of all tasks' hidden units
+            if (tt & 1) heads_step<RingX, true, true, 0>(ring, xh, xl, a10, a11, acc2, hh, hl);
+            else heads_step<RingX, true, true, 2>(ring, xh, xl, a10, a11, acc2, hh, hl);
+        } else {
+            heads_step<RingX, false, true, 2>(ring, xh, xl, a10, a11, acc2, hh, hl);           // NT even: the last step starts at 2
+        }
+        if (++t_in == T) {                                     // that was the task's last hidden tile: its 64 outputs are complete
+            float dot = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (u < 7) ring.read4_dyn(nxt);
-                group6(cur, xh[u], xl[u], a10, a11);
-                if (u < 7) {
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 w = param4(pb, G.hw3[task], t);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) cur[v] = nxt[v];
-                }
+                for (int r = 0; r < 4; ++r) dot += fmaxf(acc2[t][r] * un2, 0.f) * w[r];
             }
-            hidden_planes(a10, a11, c1, lim1, hh, hl);
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                ring.read4_dyn(cur);
-                group6(cur, hh, hl, acc2[2 * pr], acc2[2 * pr + 1]);
+            dot = reduce_sum4(dot);
+            if (g == 0 && row_ok) out[(long long)task * ld_out + row] = dot + pb[G.hb3[task]];  // g == 0: pb carries no offset
+            t_in = 0;
+            if (++task < P.n_tasks) {
+                init_pair(acc2[0], acc2[1], pb, G.hb2[task], 0, P.sw2 * sh);
+                init_pair(acc2[2], acc2[3], pb, G.hb2[task], 2, P.sw2 * sh);
             }
         }
-        float dot = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4 w = param4(pb, G.hw3[task], t);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dot += fmaxf(acc2[t][r] * un2, 0.f) * w[r];
-        }
-        dot = reduce_sum4(dot);
-        if (g == 0 && row_ok) out[(long long)task * ld_out + row] = dot + pb[G.hb3[task]];      // g == 0: pb carries no offset
     }
 }
 

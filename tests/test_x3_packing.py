@@ -251,18 +251,24 @@ def test_16_row_variant_stream_order_and_k_permutation():
         wc = f64(f"feature_interaction.cross_weights.{c}")
         got = gemm256_quarters() / p.x3.sw_cross[c]
         assert np.abs(got - x @ wc).max() <= 1e-5 * np.abs(x @ wc).max(), ("cross", c)
+    # heads, pipelined: step tt = stage 1 of hidden tile tt (through all tasks) with stage 2 of tile tt - 1 behind u = 3, 7
     xb = _b16(x)
+    T, nt = 8, 8 * len(tasks)
+    acc2 = {t: [np.zeros((16, 16), F) for _ in range(4)] for t in tasks}
+    hb = None
+    for tt in range(nt + 1):
+        a1 = [np.zeros((16, 16), F), np.zeros((16, 16), F)]
+        for u in range(8):
+            if tt < nt:
+                _group(st, xb[u], a1, 0)
+            if tt >= 1 and u in (3, 7):
+                _group(st, hb, acc2[tasks[(tt - 1) // T]], 2 * (u // 4))
+        if tt < nt:
+            b1 = f64(f"prediction_heads.{tasks[tt // T]}.0.bias")
+            hb = _hidden16(np.maximum(rows(a1) / p.x3.sw_h1 + b1[32 * (tt % T):32 * (tt % T) + 32][None, :], 0))
     for t in tasks:
         w1, b1, w2 = f64(f"prediction_heads.{t}.0.weight"), f64(f"prediction_heads.{t}.0.bias"), f64(f"prediction_heads.{t}.3.weight")
-        acc2 = [np.zeros((16, 16), F) for _ in range(4)]
-        for tt in range(8):
-            a1 = [np.zeros((16, 16), F), np.zeros((16, 16), F)]
-            for u in range(8):
-                _group(st, xb[u], a1, 0)
-            hb = _hidden16(np.maximum(rows(a1) / p.x3.sw_h1 + b1[32 * tt:32 * tt + 32][None, :], 0))
-            for pr in range(2):
-                _group(st, hb, acc2, 2 * pr)
-        got = rows(acc2) / p.x3.sw_h2
+        got = rows(acc2[t]) / p.x3.sw_h2
         ref = np.maximum(x @ w1.T + b1, 0) @ w2.T
         assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), ("head", t)
     assert st.pos == stream.shape[0]
