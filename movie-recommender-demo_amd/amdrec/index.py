@@ -263,12 +263,18 @@ class FAISSIndex:
         -> (ids int64 [nq,k], scores float32 [nq,k]) on the device.  ``return_positions``: corpus
         positions (+ ``pos_offset``, the shard's first global row) instead of ids, -1 = unfilled."""
         q = _lib.require_gpu(queries, "queries")
-        q = q.to(dtype=torch.float32, copy=True) if normalize else q
         if q.dim() != 2 or q.shape[1] != self.dimension:
             raise ValueError(f"expected [nq, {self.dimension}] queries, got {tuple(q.shape)}")
-        q = q.contiguous()
         if normalize:
-            self._normalize_(q)                                      # :146-147
+            # faiss.normalize_L2 on the wrapper's copy (:146-147): ONE out-of-place launch (a float32 contiguous input is
+            # read where it lies; the caller's tensor is never written) instead of a copy launch + an in-place one
+            src = q.to(dtype=torch.float32).contiguous()
+            q = torch.empty_like(src)
+            if src.shape[0]:
+                _lib.check(_lib.load().amdrec_l2_normalize(_lib.ptr(src), src.stride(0), _lib.ptr(q), q.stride(0), src.shape[0],
+                                                           self.dimension, _lib.stream_ptr(self.device)))
+        else:
+            q = q.contiguous()
         nq = q.shape[0]
         scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         pos = torch.empty((nq, k), dtype=torch.int64, device=self.device)

@@ -49,7 +49,8 @@ constexpr int DMA_PER_WAVE = CHUNK_FRAGS / WAVES;     // 2 fragment sets per wav
 //      +2 % SLOWER, like its run-time-branch form (removed); also removed after losing their A/Bs: fragment prefetch
 //      carried across step / phase boundaries (16 more live registers: 19 -> 51 spilled, +2.5 %) and a third fragment
 //      buffer for a two-group read-ahead (+2.5 %, and no faster even with DMA and barrier compiled out: the fragment
-//      reads cost 0.5 ms of the launch by their LDS -> VGPR traffic, not by exposed latency).
+//      reads cost 0.5 ms of the launch by their LDS -> VGPR traffic, not by exposed latency); an FFN step's first group
+//      requested at the end of the previous step, ahead of the hidden-tile conversion (+0.5 %: 12 more spilled registers).
 #ifndef AMDREC_X3B_OPT
 #define AMDREC_X3B_OPT 71
 #endif

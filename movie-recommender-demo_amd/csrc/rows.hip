@@ -98,6 +98,54 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* logits, l
     }
 }
 
+// The same for small top_k (<= 32: the serving path's top-10 of 500) without a sort: ONE WAVE per user holds the user's
+// keys in registers (KPL per lane, k_c <= 64 * KPL) and extracts the maximum top_k times (wave max by lane exchange, the
+// unique holder retires its key).  Keys are unique (the slot is part of the key), so the order is the sort's.  The
+// 512-key bitonic sort above takes ~20 us of barriers whatever the batch; this takes ~3.
+template <int KPL>
+__global__ __launch_bounds__(256) void select_topk_small_kernel(const float* logits, long long ld, int n_tasks, int rank_task,
+                                                                const long long* cand_ids, int k_c, int top_k,
+                                                                long long* out_ids, float* out_scores, int* out_slots,
+                                                                long long n_users) {
+    const int lane = threadIdx.x & 63;
+    const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= n_users) return;                                  // wave-uniform
+    const float* lr = logits + (long long)rank_task * ld + u * k_c;
+    unsigned long long key[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int i = lane + 64 * j;
+        unsigned long long kk = 0ull;
+        if (i < k_c) {
+            const float v = lr[i];
+            kk = (v == v) ? make_key(v, (uint32_t)i) : ((unsigned long long)(~(uint32_t)i) | (1ull << 32));   // NaN ranks last
+        }
+        key[j] = kk;
+    }
+    for (int r = 0; r < top_k; ++r) {
+        unsigned long long m = key[0];
+#pragma unroll
+        for (int j = 1; j < KPL; ++j) m = key[j] > m ? key[j] : m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(m, o, 64);
+            m = other > m ? other : m;
+        }
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) key[j] = key[j] == m ? 0ull : key[j];      // retire the winner (0 = empty)
+        if (lane == 0) {
+            const bool valid = r < k_c && m != 0ull;
+            const int slot = valid ? (int)key_pos(m) : -1;
+            out_ids[u * top_k + r] = valid ? cand_ids[u * k_c + slot] : -1;
+            if (out_slots) out_slots[u * top_k + r] = slot;
+            for (int t = 0; t < n_tasks; ++t) {
+                const float x = valid ? logits[(long long)t * ld + u * k_c + slot] : -INFINITY;
+                out_scores[((long long)t * n_users + u) * top_k + r] = 1.0f / (1.0f + expf(-x));
+            }
+        }
+    }
+}
+
 }  // namespace amdrec
 
 using namespace amdrec;
@@ -123,6 +171,18 @@ extern "C" int amdrec_select_topk(const float* logits, int64_t ld_logits, int n_
     if (n_users <= 0) return AMDREC_OK;
     REQUIRE(logits && cand_ids && out_ids && out_scores, "null pointer");
     REQUIRE(ld_logits >= n_users * k_c, "ld_logits too small");
+    if (top_k <= 32 && k_c <= 512) {                            // one wave per user, no sort
+        const dim3 grid((unsigned)((n_users + 3) / 4));
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        if (k_c <= 128)
+            hipLaunchKernelGGL(select_topk_small_kernel<2>, grid, dim3(256), 0, st, logits, (long long)ld_logits, n_tasks, rank_task,
+                               (const long long*)cand_ids, k_c, top_k, (long long*)out_ids, out_scores, out_slots, (long long)n_users);
+        else
+            hipLaunchKernelGGL(select_topk_small_kernel<8>, grid, dim3(256), 0, st, logits, (long long)ld_logits, n_tasks, rank_task,
+                               (const long long*)cand_ids, k_c, top_k, (long long*)out_ids, out_scores, out_slots, (long long)n_users);
+        HIP_TRY(hipGetLastError());
+        return AMDREC_OK;
+    }
     int P = 2;
     while (P < k_c) P <<= 1;
     hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)n_users), dim3(256), (size_t)P * 8,
