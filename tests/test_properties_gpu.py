@@ -76,3 +76,48 @@ def test_corpus_build_1m_rows_through_ad_tower_and_index():
     ids, D = idx.search(ref[:8], 3)                        # each row retrieves itself (duplicates may tie)
     assert np.all(np.abs(D[:, 0] - 1.0) <= 1e-5)
     assert all(np.array_equal(table[ids[i, 0]], table[rows[i]]) for i in range(8))
+
+
+@pytest.mark.parametrize("k_c,top_k", [(500, 10), (100, 10), (500, 32), (7, 10), (500, 64), (600, 10)])
+def test_select_topk_both_kernels_ties_nan_and_short_lists(k_c, top_k):
+    """amdrec_select_topk (np.argsort(ctr)[::-1][:top_k] of inference.py:263, on logits): order (logit desc, candidate slot
+    asc) on ties, NaN logits last, sigmoid of every task at the winners, -1 / 0-probability padding when a user has fewer
+    than top_k candidates.  top_k <= 32 with <= 512 candidates takes the one-wave-per-user kernel (no sort), everything
+    else the LDS bitonic sort: both must agree with numpy's lexsort."""
+    import ctypes as C
+    from amdrec import _lib
+    lib = _lib.load()
+    U, T = 9, 3
+    rng = np.random.default_rng(k_c * 131 + top_k)
+    logits = rng.standard_normal((T, U * k_c)).astype(np.float32)
+    lg = logits[0].reshape(U, k_c)
+    lg[1, :] = 0.25                                            # all tied: the lowest slots win, in order
+    if k_c > 5:
+        lg[2, ::3] = lg[2, 1]                                  # many ties scattered
+        lg[3, [0, 4]] = np.nan                                 # NaN ranks last
+        lg[4, :] = -np.inf
+    logits[0] = lg.reshape(-1)
+    cand = rng.permutation(10_000_000)[:U * k_c].reshape(U, k_c).astype(np.int64)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()          # noqa: E731
+    L, Cd = d(logits), d(cand)
+    ids = torch.full((U, top_k), -7, dtype=torch.int64, device="cuda")
+    sc = torch.full((T, U, top_k), -7.0, dtype=torch.float32, device="cuda")
+    slots = torch.full((U, top_k), -7, dtype=torch.int32, device="cuda")
+    _lib.check(lib.amdrec_select_topk(_lib.ptr(L), L.stride(0), T, 0, _lib.ptr(Cd), U, k_c, top_k, _lib.ptr(ids), _lib.ptr(sc),
+                                      _lib.ptr(slots), _lib.stream_ptr(L.device)))
+    torch.cuda.synchronize()
+    ids, sc, slots = ids.cpu().numpy(), sc.cpu().numpy(), slots.cpu().numpy()
+    n = min(k_c, top_k)
+    for u in range(U):
+        v = lg[u].astype(np.float64)
+        key = np.where(np.isnan(v), -np.inf, v)                # NaN last; among NaNs (and -inf) lower slot first
+        nan_last = np.isnan(v).astype(np.int64)
+        order = np.lexsort((np.arange(k_c), -key, nan_last))[:n]
+        assert slots[u, :n].tolist() == order.tolist(), (u, slots[u], order)
+        assert ids[u, :n].tolist() == cand[u][order].tolist()
+        for t in range(T):
+            x = logits[t].reshape(U, k_c)[u][order].astype(np.float64)
+            want = 1.0 / (1.0 + np.exp(-x))
+            got = sc[t, u, :n]
+            assert np.allclose(got[~np.isnan(x)], want[~np.isnan(x)], atol=1e-6)
+        assert (ids[u, n:] == -1).all() and (slots[u, n:] == -1).all() and (sc[:, u, n:] == 0).all()
