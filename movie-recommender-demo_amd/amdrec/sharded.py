@@ -30,6 +30,7 @@ engine is the HIP one and refuses CPU tensors.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -183,6 +184,8 @@ class ShardedRecommender:
         self._recent = []                    # 1 per verified short-list batch that had to be repeated, else 0 (window)
         self.stats = {"batches": 0, "queries": 0, "unproven_queries": 0, "repeated_batches": 0, "switched_off": False}
         self.last_exchange = None            # {"kind", "bytes_per_rank", "list_k"} of the most recent step
+        self._side = None                    # side stream + pinned flag of the asynchronous proof read (_proof_begin)
+        self._host_flag = None
 
     def list_k(self, stage1_k: int) -> int:
         if self.shard_k is None or self.world <= 1:
@@ -216,25 +219,69 @@ class ShardedRecommender:
         all-reduce + a device sync) and a failed batch is recomputed with full lists; ``verify=False`` leaves the check
         to the caller (``inexact_count()``, e.g. once per reporting interval)."""
         kq = self.list_k(stage1_k)
-        out = self._step(user_categorical, user_numerical, top_k, stage1_k, kq)
-        if kq < stage1_k and verify:
-            bad = self.inexact_count()                                        # identical on every rank (all-reduce)
-            B = int(user_categorical.shape[0])
-            st = self.stats
-            st["batches"] += 1
-            st["queries"] += B
-            st["unproven_queries"] += bad
-            self._recent = (self._recent + [1 if bad else 0])[-SHORT_LIST_WINDOW:]
-            if bad:
-                # per-batch fallback: only this batch pays the second exchange; the decision to give short lists up for
-                # good needs more than an occasional unlucky query (every rank sees the same counts: same decision)
-                st["repeated_batches"] += 1
-                out = self._step(user_categorical, user_numerical, top_k, stage1_k, stage1_k)
-                often = len(self._recent) >= 4 and sum(self._recent) > SHORT_LIST_MAX_REPEAT_FRAC * len(self._recent)
-                if bad > SHORT_LIST_MAX_FAIL_FRAC * B or often:
-                    self.shard_k = None                                       # this corpus is not randomly sharded
-                    st["switched_off"] = True
+        if not (kq < stage1_k and verify):
+            return self._step(user_categorical, user_numerical, top_k, stage1_k, kq)
+        # The proof is read BETWEEN the merge and the ranker launch, on a side stream: the host blocks only until the 4-byte
+        # all-reduce and its copy have landed while the ranker (2.7 ms) runs, so the next step's launches queue up behind it
+        # as in the unverified mode.  (Reading the counter after the step - one .item() on the launch stream - parks the
+        # host until the ranker is done and exposes the next step's ~0.3 ms of launch work: 6 % in the 2-rank rehearsal.)
+        proof = []
+        out = self._step(user_categorical, user_numerical, top_k, stage1_k, kq, after_merge=lambda: proof.append(self._proof_begin()))
+        bad = self._proof_end(proof[0])                                       # identical on every rank (all-reduce)
+        B = int(user_categorical.shape[0])
+        st = self.stats
+        st["batches"] += 1
+        st["queries"] += B
+        st["unproven_queries"] += bad
+        self._recent = (self._recent + [1 if bad else 0])[-SHORT_LIST_WINDOW:]
+        if bad:
+            # per-batch fallback: only this batch pays the second exchange; the decision to give short lists up for
+            # good needs more than an occasional unlucky query (every rank sees the same counts: same decision)
+            st["repeated_batches"] += 1
+            out = self._step(user_categorical, user_numerical, top_k, stage1_k, stage1_k)
+            often = len(self._recent) >= 4 and sum(self._recent) > SHORT_LIST_MAX_REPEAT_FRAC * len(self._recent)
+            if bad > SHORT_LIST_MAX_FAIL_FRAC * B or often:
+                self.shard_k = None                                       # this corpus is not randomly sharded
+                st["switched_off"] = True
         return out
+
+    def _proof_begin(self):
+        """Start reading the proof counter (queries of this step not proven exact, summed over the ranks) right behind the
+        merge: clone + reset on the launch stream, all-reduce, copy to pinned host memory on a side stream.  -> handle for
+        ``_proof_end``.  Under a gloo group with device tensors (rehearsal) and for CPU engines the read is synchronous."""
+        if self._inexact is None:
+            return ("value", 0)
+        t = self._inexact.clone()
+        self._inexact.zero_()
+        if not t.is_cuda or self.world <= 1 or dist.get_backend(self.group) == "gloo" or os.environ.get("AMDREC_SYNC_PROOF") == "1":
+            return ("sync", t)
+        work = dist.all_reduce(t, group=self.group, async_op=True)            # waits for the merge, not for what follows
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=t.device)
+            self._host_flag = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        with torch.cuda.stream(self._side):
+            work.wait()                                                       # the SIDE stream waits for the collective
+            t.record_stream(self._side)
+            self._host_flag.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return ("async", ev, t)
+
+    def _proof_end(self, handle) -> int:
+        if handle[0] == "value":
+            return handle[1]
+        if handle[0] == "async":
+            handle[1].synchronize()                                           # all-reduce + 4-byte copy; the ranker keeps running
+            return int(self._host_flag.item())
+        t = handle[1]
+        if self.world > 1:
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t = h
+            else:
+                dist.all_reduce(t, group=self.group)
+        return int(t.item())
 
     def short_list_stats(self):
         """Verified short-list batches so far: queries proven exact on the first exchange / all queries (hit rate),
@@ -243,8 +290,9 @@ class ShardedRecommender:
         st["hit_rate"] = 1.0 - st["unproven_queries"] / st["queries"] if st["queries"] else None
         return st
 
-    def _step(self, uc, un, top_k: int, k_out: int, k: int):
-        """One exchange with lists of k entries per shard, merged to k_out candidates per user."""
+    def _step(self, uc, un, top_k: int, k_out: int, k: int, after_merge=None):
+        """One exchange with lists of k entries per shard, merged to k_out candidates per user.  ``after_merge``: called once
+        the merge is enqueued, before the ranker is (the proof read of the verified mode)."""
         B = uc.shape[0]
         scores, pos = self.engine.local_search(uc, un, k)                     # [B,k] each
         q0, nq = user_slice(B, self.rank, self.world)
@@ -275,6 +323,8 @@ class ShardedRecommender:
             all_gather_bytes(gathered, buf, self.group)                       # ONE collective per step
             self.last_exchange = {"kind": "all_gather", "bytes_per_rank": int(buf.numel()), "list_k": k}
             cand_scores, cand_pos = self._merge(gathered, B, k, q0, nq, k_out, inexact)
+        if after_merge is not None:
+            after_merge()
         out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
         out["candidate_scores"] = cand_scores
         out["user_offset"] = q0

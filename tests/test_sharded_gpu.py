@@ -191,5 +191,18 @@ def test_sharded_recommender_single_rank_rccl_matches_pipeline():
         all_gather_bytes(d2, src)
         torch.cuda.synchronize()
         assert torch.equal(d1, src) and torch.equal(d2, src)
+        # the asynchronous proof read of the verified short-list mode (all-reduce with async_op, side stream, pinned flag)
+        # over real RCCL: with one rank the sum is the rank's own counter.  (`world = 2` only selects the code path; the
+        # collective runs on the 1-rank group.)
+        sr2 = ShardedRecommender(rec, 0, 1, shard_offset=0)
+        sr2.world = 2
+        for want in (3, 0, 41):
+            sr2._inexact = torch.tensor([want], dtype=torch.int32, device="cuda")
+            busy = torch.randn(4096, 4096, device="cuda") @ torch.randn(4096, 4096, device="cuda")     # work queued behind it
+            h = sr2._proof_begin()
+            busy = busy @ busy                                                                          # ... and after it
+            assert h[0] == "async" and sr2._proof_end(h) == want
+            assert int(sr2._inexact.item()) == 0                                                        # read-and-reset
+        del busy
     finally:
         dist.destroy_process_group()
