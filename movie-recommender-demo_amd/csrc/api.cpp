@@ -38,7 +38,7 @@ hipEvent_t get_event() {
     return e;
 }
 }  // namespace
-ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : slot(-1), st(s) {
+ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : end(nullptr), st(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_only.empty() && strncmp(tag, g_only.c_str(), g_only.size()) != 0) return;
@@ -49,12 +49,11 @@ ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s)
     Rec r{t, get_event(), get_event()};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
-    slot = (int)g_recs.size() - 1;
+    end = r.b;
 }
 ProfScope::~ProfScope() {
-    if (slot < 0) return;
-    std::lock_guard<std::mutex> lk(g_mu);
-    (void)hipEventRecord(g_recs[slot].b, st);
+    if (end == nullptr) return;
+    (void)hipEventRecord(end, st);          // events are pooled, never destroyed: valid even if the table was reset meanwhile
 }
 }  // namespace amdrec
 

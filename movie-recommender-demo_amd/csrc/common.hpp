@@ -85,8 +85,8 @@ struct PerDeviceOnce {
 // ---- optional per-launch timing (amdrec_profile_*): HIP events recorded on the launch stream
 // around each GEMM launch, accumulated per kernel tag.  Off by default (zero cost).
 struct ProfScope {
-    int slot;
-    hipStream_t st;
+    hipEvent_t end;          // nullptr: not timed.  The scope keeps the EVENT, not an index into the record table: another
+    hipStream_t st;          // thread may reset the table (amdrec_profile_enable) between this scope's two ends
     ProfScope(const char* tag, double flops, double bytes, hipStream_t st);
     ~ProfScope();
 };
