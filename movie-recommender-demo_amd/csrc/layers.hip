@@ -535,6 +535,12 @@ extern "C" int amdrec_tower_workspace(const amdrec_tower_params* p, int64_t rows
     return AMDREC_OK;
 }
 
+namespace amdrec {   // tower_small.hip: the whole tower in one launch for batches of <= 4096 rows
+bool tower_small_ok(const amdrec_tower_params* p, long long rows);
+hipError_t tower_small_run(const amdrec_tower_params* p, const long long* cat, const float* num, long long rows, float* out,
+                           long long ld_out, hipStream_t st);
+}
+
 extern "C" int amdrec_tower_forward(const amdrec_tower_params* p, const int64_t* cat, const float* num,
                                     int64_t rows, float* out, int64_t ld_out, int* bad_index_flag,
                                     void* workspace, size_t workspace_bytes, void* stream) {
@@ -556,6 +562,10 @@ extern "C" int amdrec_tower_forward(const amdrec_tower_params* p, const int64_t*
         long long n = rows * p->n_feat;
         hipLaunchKernelGGL(check_index_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            (const long long*)cat, (long long)rows, p->n_feat, p->cards, bad_index_flag);
+    }
+    if (tower_small_ok(p, rows)) {                      // serving batches: one launch for the whole tower
+        HIP_TRY(tower_small_run(p, (const long long*)cat, num, rows, out, (long long)ld_out, st));
+        return AMDREC_OK;
     }
     for (long long r0 = 0; r0 < rows; r0 += chunk) {
         const long long m = rows - r0 < chunk ? rows - r0 : chunk;

@@ -1,0 +1,203 @@
+// Small batches of the two-tower forward (two_tower_model.py:98-121 / :167-184, eval mode, BatchNorm folded) in ONE launch.
+//
+// amdrec_tower_forward's general path is one tiled-GEMM launch per layer; for the serving path's batches (one request,
+// or 512 users per step) each of those launches is latency-bound - a UserTower took 12 + 23 + 14 us in three kernels of
+// 16-32 workgroups each (kernel trace, profiles/r03_trace_b1.log).  Here a workgroup of 8 waves owns 16 rows through the
+// WHOLE tower:
+//   * the gathered input row (embedding lookups of two_tower_model.py:33-49 + the numerical features, zero-padded to a
+//     multiple of 128) and every layer's activations live in LDS (two ping-pong buffers of 16 x width floats);
+//   * a layer is width / 16 output tiles of 16 features, dealt in pairs to the waves; a tile is K / 4
+//     v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate - the arithmetic of the general path's fp32 MFMA);
+//     A = weights straight from global memory (each element is used once per workgroup: a lane loads 16 B of its feature's
+//     row = 4 k values = 4 MFMAs; the k index a lane group supplies is permuted the same way for both operands), B = the
+//     activations from LDS (one ds_read_b128 per 4 MFMAs, shared by the pair of tiles);
+//   * what bounds a tile is the latency of its weight loads, so they are issued in straight-line chunks of up to 16
+//     k-steps (32 loads of 16 B per lane in flight) in front of the chunk's MFMAs, which then start as the data arrives
+//     (counted vmcnt waits).  Chunks are compile-time sized: a conditional inside the pipeline makes the compiler wait
+//     for every outstanding load at the join (two earlier versions with run-time step predicates: 74 and 54 us);
+//   * bias + ReLU go back to LDS; the last layer's rows are L2-normalised (x / max(||x||, 1e-12), F.normalize) and written
+//     with 16-byte stores.
+// Same inputs and layout contract as the general path (weights [out][ldw], K zero-padded to a multiple of 32); indices are
+// clamped into their tables like EmbConcatRows does (a bad index is reported by check_index_kernel, never dereferenced).
+#include "gemm_core.hpp"
+#include "../../include/amdrec.h"
+
+namespace amdrec {
+
+constexpr int TS_ROWS = 16, TS_WAVES = 8;
+constexpr long long TS_MAX_ROWS = 4096;      // one 16-row workgroup per CU; beyond it the tiled GEMMs have enough work per launch
+constexpr int TS_MAX_WIDTH = 1024;
+
+struct TowerSmallArgs {
+    EmbConcatRows in;
+    int n_layers;
+    int dims[AMDREC_MAX_LAYERS + 1];
+    int kp[AMDREC_MAX_LAYERS];                 // K of layer l as the kernel walks it: dims[l] rounded up (layer 0: to 128)
+    int ldw[AMDREC_MAX_LAYERS];
+    const float* w[AMDREC_MAX_LAYERS];
+    const float* b[AMDREC_MAX_LAYERS];
+    float* out;
+    long long ld_out;
+    long long rows;
+    int ld_act;                                // floats between the rows of an activation buffer
+};
+
+// LDS pointers keep their address space: through a generic pointer (e.g. an array of two buffer pointers indexed at run time)
+// every activation read becomes a FLAT load, which the compiler must wait for with vmcnt(0) - draining the weight loads in
+// flight at every k-step.
+typedef __attribute__((address_space(3))) float lds_f32;
+
+// STEPS k-steps (16 k each) of a pair of output tiles: every weight load first, then the MFMAs, each step behind a COUNTED
+// wait for its own two loads.  Loads and waits are inline asm: left to the compiler, the first MFMA waited for ALL loads of the
+// chunk (s_waitcnt vmcnt(0)) and the chunk's memory latency was never overlapped with its own arithmetic.  The chunk is the
+// only vector-memory traffic of a wave at this point (the input gather ended at a barrier), loads return in issue order, and
+// each wait names the registers it releases, so no MFMA can be scheduled ahead of it.
+template <int STEPS>
+__device__ __forceinline__ void tower_chunk(const float* w0, const float* w1, const lds_f32* src, f32x4& acc0, f32x4& acc1) {
+    f32x4 a0[STEPS], a1[STEPS];
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(a0[i]) : "v"(w0), "n"(64 * i));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(a1[i]) : "v"(w1), "n"(64 * i));
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(src + 16 * i);
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a0[i]), "+v"(a1[i]) : "n"(2 * (STEPS - 1 - i)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], bv[e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][e], bv[e], acc1, 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * TS_WAVES) void tower_small_kernel(TowerSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float act[];         // [2][TS_ROWS][ld_act]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const long long row0 = (long long)blockIdx.x * TS_ROWS;
+    const int LD = a.ld_act;
+    lds_f32* const act3 = (lds_f32*)act;
+    auto buf = [&](int i) -> lds_f32* { return act3 + (i & 1) * (TS_ROWS * LD); };
+    // input rows -> buf[0][row][0 .. kp[0]), zero beyond dims[0] (EmbConcatRows::load returns zeros there)
+    {
+        const int chunks = a.kp[0] >> 2;
+        for (int i = tid; i < TS_ROWS * chunks; i += 64 * TS_WAVES) {
+            const int r = i / chunks, k = (i - r * chunks) << 2;
+            const f32x4 v = a.in.load(a.in.row_state(row0 + r), k);           // rows past the end are clamped, never written out
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(buf(0) + r * LD + k) = v;
+        }
+    }
+    __syncthreads();
+    for (int l = 0; l < a.n_layers; ++l) {
+        const float* __restrict__ W = a.w[l];
+        const float* __restrict__ bias = a.b[l];
+        const int ldw = a.ldw[l], nout = a.dims[l + 1];
+        const int steps = a.kp[l] >> 4;                                      // kp <= ldw, weights and activations zero beyond K
+        const bool last = l == a.n_layers - 1;
+        const lds_f32* src0 = buf(l) + n * LD + 4 * g;
+        lds_f32* dst = buf(l + 1);
+        const int tiles = nout >> 4;
+        for (int t = 2 * wave; t < tiles; t += 2 * TS_WAVES) {               // a pair of output tiles per turn (wave-uniform)
+            const bool two = t + 1 < tiles;
+            const float* w0 = W + (long long)(16 * t + n) * ldw + 4 * g;    // A: lane (i = n) is output feature 16 t + n
+            const float* w1 = two ? w0 + 16ll * ldw : w0;
+            const lds_f32* src = src0;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            int rem = steps;                                                  // wave-uniform walk in compile-time chunks
+            while (rem >= 16) { tower_chunk<16>(w0, w1, src, acc0, acc1); w0 += 256; w1 += 256; src += 256; rem -= 16; }
+            if (rem >= 8) { tower_chunk<8>(w0, w1, src, acc0, acc1); w0 += 128; w1 += 128; src += 128; rem -= 8; }
+            if (rem >= 4) { tower_chunk<4>(w0, w1, src, acc0, acc1); w0 += 64; w1 += 64; src += 64; rem -= 4; }
+            if (rem >= 2) { tower_chunk<2>(w0, w1, src, acc0, acc1); w0 += 32; w1 += 32; src += 32; rem -= 2; }
+            if (rem >= 1) tower_chunk<1>(w0, w1, src, acc0, acc1);
+            // accumulator: lane (n, g) holds features 16 t + 4 g + {0..3} of row n
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g);
+            f32x4 y0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y0[e] = last ? acc0[e] + b0[e] : fmaxf(acc0[e] + b0[e], 0.f);
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(dst + n * LD + 16 * t + 4 * g) = y0;
+            if (two) {
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 16 * (t + 1) + 4 * g);
+                f32x4 y1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y1[e] = last ? acc1[e] + b1[e] : fmaxf(acc1[e] + b1[e], 0.f);
+                *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(dst + n * LD + 16 * (t + 1) + 4 * g) = y1;
+            }
+        }
+        __syncthreads();
+    }
+    // L2 normalisation of the last layer's rows: wave w takes rows 2 w, 2 w + 1, a lane 16 B at a time
+    const lds_f32* fin = buf(a.n_layers);
+    const int nout = a.dims[a.n_layers];
+#pragma unroll 1
+    for (int rr = 0; rr < TS_ROWS / TS_WAVES; ++rr) {
+        const int r = (TS_ROWS / TS_WAVES) * wave + rr;
+        const lds_f32* xr = fin + r * LD;
+        float ss = 0.f;
+        for (int c = 4 * lane; c < nout; c += 256) {
+            const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        if (row0 + r < a.rows) {
+            float* o = a.out + (row0 + r) * a.ld_out;
+            for (int c = 4 * lane; c < nout; c += 256) {
+                f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] / nrm;
+                *reinterpret_cast<f32x4*>(o + c) = v;
+            }
+        }
+    }
+}
+
+// eligibility: every hidden / output width a multiple of 16 (whole output tiles, and the next layer's K needs no padding)
+bool tower_small_ok(const amdrec_tower_params* p, long long rows) {
+    if (rows > TS_MAX_ROWS) return false;
+    if (p->dims[0] > TS_MAX_WIDTH || ((p->dims[0] + 127) & ~127) > p->ldw[0]) return false;   // layer 0 is walked in 128-k units
+    for (int l = 1; l <= p->n_layers; ++l)
+        if (p->dims[l] % 16 != 0 || p->dims[l] > TS_MAX_WIDTH) return false;
+    return true;
+}
+
+hipError_t tower_small_run(const amdrec_tower_params* p, const long long* cat, const float* num, long long rows, float* out,
+                           long long ld_out, hipStream_t st) {
+    TowerSmallArgs a{};
+    a.in.tables = p->tables; a.in.off = p->table_off; a.in.card = p->cards;
+    a.in.cat0 = cat; a.in.cat1 = nullptr; a.in.rowmap1 = nullptr; a.in.num = num;
+    a.in.row_base = 0; a.in.rows = rows; a.in.rows1 = rows;
+    a.in.F = p->n_feat; a.in.F0 = p->n_feat; a.in.E = p->emb_dim;
+    a.in.eshift = 31 - __builtin_clz((unsigned)p->emb_dim);                  // emb_dim is a power of two (tower_check)
+    a.in.n_num = p->n_num; a.in.cat0_rowdiv = 1;
+    a.n_layers = p->n_layers;
+    int wmax = (p->dims[0] + 127) & ~127;
+    double flops = 0;
+    for (int l = 0; l <= p->n_layers; ++l) {
+        a.dims[l] = p->dims[l];
+        if (l >= 1 && p->dims[l] > wmax) wmax = p->dims[l];
+        if (l < p->n_layers) {
+            a.kp[l] = l == 0 ? (p->dims[0] + 127) & ~127 : p->dims[l];
+            a.ldw[l] = p->ldw[l]; a.w[l] = p->w[l]; a.b[l] = p->b[l];
+            flops += 2.0 * p->dims[l] * p->dims[l + 1];
+        }
+    }
+    a.out = out; a.ld_out = ld_out; a.rows = rows;
+    a.ld_act = wmax + 4;                                  // + 16 bytes: rows of a buffer start on different banks
+    const size_t lds = 2ull * TS_ROWS * a.ld_act * sizeof(float);
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_small_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TS_ROWS * (TS_MAX_WIDTH + 4) * 4);
+        if (e != hipSuccess) return e;
+        attr_done.mark();
+    }
+    ProfScope prof("tower_fused_16rows", flops * (double)rows, (double)rows * 4.0 * (p->dims[0] + p->dims[p->n_layers]), st);
+    hipLaunchKernelGGL(tower_small_kernel, dim3((unsigned)((rows + TS_ROWS - 1) / TS_ROWS)), dim3(64 * TS_WAVES), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace amdrec
