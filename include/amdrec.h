@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMDREC_ABI_VERSION 5
+#define AMDREC_ABI_VERSION 6
 #define AMDREC_MAX_K 2048
 
 int amdrec_abi_version(void);
@@ -94,6 +94,13 @@ int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, const int64
  * With tau[q] = the k-th score over a SUBSET of the probed lists (a lower bound of the final k-th score) the union of
  * that subset's keys and the kept rows of the remaining lists contains the exact top-k: amdrec.ivf scans the nearest
  * eighth of the probes unfiltered, selects, and scans the rest with this filter - the pool shrinks ~5x. */
+/* Step 1 as a dense key table (replaces the `index.search` of faiss's IndexFlatIP quantizer inside IndexIVFFlat.search,
+ * faiss_retrieval.py:50-55, :150-155): keys[q][c] = 64-bit (score of query q against centroid c, ~c) for every centroid -
+ * the pool format of amdrec_ivf_select, which then yields the nprobe best centroids per query (score desc, lower centroid
+ * first).  Same fp32-MFMA scores as amdrec_flat_search over the centroid table, without its candidate machinery.
+ * keys: 16-byte aligned; ld_keys even and >= nlist (an odd nlist's last pair writes one padding key). */
+int amdrec_ivf_coarse_keys(const float* centroids, int nlist, int64_t ld_centroids, int dim, const float* queries,
+                           int64_t nq, int64_t ld_queries, uint64_t* keys /*[nq][ld_keys]*/, int64_t ld_keys, void* stream);
 int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count /*[nq]*/,
                       int64_t nq, int k, float* out_scores /*[nq][k]*/, int64_t* out_pos /*[nq][k]*/,
                       void* stream);

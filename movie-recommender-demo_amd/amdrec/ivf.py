@@ -77,6 +77,7 @@ class IVFState:
         self.assign = torch.empty(0, dtype=torch.int64, device=self.device)   # list of every position
         self._lists = None                                          # (xs, spos, list_off, list_len, max_len)
         self._top_rows = None                                       # host: rows of the p longest lists (pool_rows_bound)
+        self._nlist_count = None                                    # device: nlist per query (the coarse select's pool sizes)
 
     # -- build ----------------------------------------------------------------------------
     @classmethod
@@ -146,10 +147,10 @@ class IVFState:
             return
         xs, spos, off, lens, max_len, _ = self._build_lists(xb, n)
         nprobe = max(1, int(nprobe))
-        # 1. coarse quantizer: nprobe best centroids by inner product (IndexFlatIP quantizer)
+        # 1. coarse quantizer: nprobe best centroids by inner product (IndexFlatIP quantizer) = a dense (score, centroid)
+        #    key table + the pool select (step 4's kernel); runs below, once the workspace is sized
         cs = torch.empty((nq, nprobe), dtype=torch.float32, device=self.device)
         probes = torch.empty((nq, nprobe), dtype=torch.int64, device=self.device)
-        flat_search(self.centroids, self.nlist, q, nprobe, cs, probes)
         # 2. pool layout + (query, probe) pairs grouped by list: amdrec_ivf_group (kernels, no host sync)
         base = torch.empty((nq, nprobe), dtype=torch.int64, device=self.device)
         n_pool = torch.empty((nq,), dtype=torch.int64, device=self.device)
@@ -163,7 +164,20 @@ class IVFState:
         pool_bytes = (chunk * pool_ld * 8 + 255) // 256 * 256
         grp_bytes = ((self.nlist + 1) * 4 + 255) // 256 * 256 + (chunk * nprobe * 4 + 255) // 256 * 256
         arr_bytes = 2 * chunk * nprobe * 8 + 2 * (self.nlist + 1) * 8
-        wsall = _lib.WORKSPACE.get(pool_bytes + grp_bytes + arr_bytes + 256, self.device)
+        coarse_ld = (self.nlist + 1) // 2 * 2
+        coarse = nq * coarse_ld * 8 <= POOL_BYTES and nprobe <= _lib.MAX_K and nq < (1 << 24)
+        wsall = _lib.WORKSPACE.get(max(pool_bytes + grp_bytes + arr_bytes + 256, nq * coarse_ld * 8 if coarse else 0),
+                                   self.device)
+        if coarse:                                     # the key table lives in the pool's memory: the scans come after it
+            if self._nlist_count is None or self._nlist_count.numel() < nq:
+                self._nlist_count = torch.full((max(nq, 512),), self.nlist, dtype=torch.int64, device=self.device)
+            _lib.check(lib.amdrec_ivf_coarse_keys(_lib.ptr(self.centroids), self.nlist, self.centroids.stride(0), self.dim,
+                                                  _lib.ptr(q), nq, q.stride(0), _lib.ptr(wsall), coarse_ld,
+                                                  _lib.stream_ptr(self.device)))
+            _lib.check(lib.amdrec_ivf_select(_lib.ptr(wsall), coarse_ld, _lib.ptr(self._nlist_count), nq, nprobe,
+                                             _lib.ptr(cs), _lib.ptr(probes), _lib.stream_ptr(self.device)))
+        else:
+            flat_search(self.centroids, self.nlist, q, nprobe, cs, probes)
         ws = wsall[:pool_bytes]
         grp = wsall[pool_bytes:pool_bytes + grp_bytes]
         arr = wsall[pool_bytes + grp_bytes:pool_bytes + grp_bytes + arr_bytes].view(torch.int64)

@@ -22,7 +22,7 @@ int set_error(int code, const char* fmt, ...) {
 #include <string>
 #include <vector>
 namespace amdrec {
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};  // read without the lock on every entry (relaxed is enough: a scope that misses a toggle is untimed)
 namespace {
 struct Rec { int tag; hipEvent_t a, b; };
 struct Tag { std::string name; long long launches; double ms, flops, bytes; };

@@ -1,6 +1,7 @@
 // Common device/host helpers for libamdrec (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -90,6 +91,6 @@ struct ProfScope {
     ProfScope(const char* tag, double flops, double bytes, hipStream_t st);
     ~ProfScope();
 };
-extern bool g_prof_on;
+extern std::atomic<bool> g_prof_on;
 
 }  // namespace amdrec

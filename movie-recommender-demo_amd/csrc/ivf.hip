@@ -139,6 +139,51 @@ struct EpiIvfKeys {
     }
 };
 
+// Coarse quantizer as a dense key table (round 3): scores of every query against every centroid -> keys[nq][ld] (64-bit
+// (score, ~centroid), the pool format of ivf_select).  The probes used to come from the general exact search
+// (amdrec_flat_search over the centroid table): with nlist <= 8192 rows that path files EVERY row as a candidate through
+// atomics and sorts 4096 keys per query - 0.27 ms of a 4.6 ms step at nlist 4096 / 512 queries.  Same mainloop, same
+// operand roles (lane <-> query, registers <-> centroids) as that search's filter pass, so the scores - and with
+// ivf_select's order rule (score desc, position asc) the probes - are bit-identical to it.
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+struct EpiCoarseKeys {
+    static constexpr const char* name = "ivf_coarse";
+    static constexpr double out_bytes_per_elem = 2.0;
+    static constexpr size_t lds_bytes(int) { return 0; }
+    unsigned long long* keys;   // [nq][ld]
+    long long ld;
+    int nq;
+    long long nlist;
+    template <class A>
+    __device__ void operator()(A& acc, float*) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const int q = acc.q(j, lane);
+            if (q >= nq) continue;
+            unsigned long long* dst = keys + (long long)q * ld;
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const long long p = acc.p(i, 4 * g, lane);     // 4 consecutive centroids p .. p+3
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        if (p + e >= nlist) continue;
+                        float s0 = acc.v[i][j][4 * g + e], s1 = acc.v[i][j][4 * g + e + 1];
+                        if (!(s0 == s0)) s0 = -INFINITY;            // NaN scores rank last (as in the list scan)
+                        if (!(s1 == s1)) s1 = -INFINITY;
+                        u64x2 kk;
+                        kk[0] = make_key(s0, (uint32_t)(p + e));
+                        kk[1] = make_key(s1, (uint32_t)(p + e + 1)); // p+e+1 == nlist (odd nlist): lands in the ld padding
+                        *reinterpret_cast<u64x2*>(dst + p + e) = kk;
+                    }
+                }
+        }
+    }
+};
+
 using ShapeIvf = Shape<2, 2, 1, 4>;     // 64 queries x 256 list rows per workgroup
 using ShapeIvf32 = Shape<1, 4, 1, 2>;   // 32 queries x 256 list rows: for sparse groups (few probing queries per list: 512 x 64
                                         // probes over 4096 lists is 8 per list, a 64-query tile would be 12 % full)
@@ -565,6 +610,30 @@ extern "C" int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, 
                                           (const long long*)pair_query, (const long long*)pair_probe, (const long long*)pool_base,
                                           nprobe, (unsigned long long*)pool_keys, pool_ld, pos_offset, tau, (long long)ld_tau,
                                         (unsigned long long*)pool_fill, st);
+    HIP_TRY(e);
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_ivf_coarse_keys(const float* centroids, int nlist, int64_t ld_centroids, int dim, const float* queries,
+                                      int64_t nq, int64_t ld_queries, uint64_t* keys, int64_t ld_keys, void* stream) {
+    REQUIRE(dim >= 4 && dim % 4 == 0 && dim <= 2048, "dim=%d must be a multiple of 4 in [4,2048]", dim);
+    REQUIRE(nlist >= 1 && nlist <= (1 << 20), "nlist out of range");
+    if (nq <= 0) return AMDREC_OK;
+    REQUIRE(centroids && queries && keys, "null pointer");
+    REQUIRE(ld_centroids >= dim && ld_centroids % 4 == 0 && ld_queries >= dim && ld_queries % 4 == 0 && ld_keys >= (nlist + 1) / 2 * 2 &&
+                ld_keys % 2 == 0,
+            "bad leading dimension");
+    REQUIRE(((uintptr_t)centroids % 16) == 0 && ((uintptr_t)queries % 16) == 0, "centroids / queries must be 16-byte aligned");
+    REQUIRE(((uintptr_t)keys % 16) == 0, "keys must be 16-byte aligned");
+    REQUIRE(nq < (1ll << 24), "nq out of range");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DenseRows lp{centroids, nlist, (int)ld_centroids, dim, 30, 1ll << 30};
+    DenseRows lq{queries, nq, (int)ld_queries, dim, 30, 1ll << 30};
+    EpiCoarseKeys epi{reinterpret_cast<unsigned long long*>(keys), (long long)ld_keys, (int)nq, (long long)nlist};
+    hipError_t e;                                       // the query-tile shapes of amdrec_flat_search's filter pass
+    if (nq > 64)      e = launch_gemm<Shape<2, 2, 4, 2>, false>(lp, lq, epi, dim, nlist, nq, st);
+    else if (nq > 32) e = launch_gemm<Shape<4, 1, 2, 2>, false>(lp, lq, epi, dim, nlist, nq, st);
+    else              e = launch_gemm<Shape<4, 1, 2, 1>, false>(lp, lq, epi, dim, nlist, nq, st);
     HIP_TRY(e);
     return AMDREC_OK;
 }

@@ -245,3 +245,33 @@ def test_two_phase_grouped_scan_with_ties_at_tau(n, nlist, k, copies):
         assert bool((pool1 < k).any())                          # tau = -inf for those queries: the filter keeps everything
     else:
         assert bool((pool1 >= k).any())                         # tau is a real score there, with copies tying at it
+
+
+@pytest.mark.parametrize("nlist,nprobe,nq", [(37, 5, 300), (4096, 64, 70), (1000, 1000, 3), (257, 16, 33), (100, 10, 1)])
+def test_coarse_key_table_gives_the_exact_search_probes(nlist, nprobe, nq):
+    """amdrec_ivf_coarse_keys + amdrec_ivf_select == amdrec_flat_search over the centroid table, bit for bit (scores and
+    centroid ids, ties towards the lower id): the IndexFlatIP quantizer of IndexIVFFlat (faiss_retrieval.py:118)."""
+    from amdrec import _lib
+    from amdrec.index import flat_search
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(nlist + nq)
+    cent = torch.nn.functional.normalize(torch.randn(nlist, 256, generator=g), dim=1)   # unit rows: SCORE_ATOL applies
+    cent[nlist // 2] = cent[0]                       # a duplicated centroid: equal scores, the lower id first
+    cent = cent.cuda()
+    q = torch.nn.functional.normalize(torch.randn(nq, 256, generator=g), dim=1).cuda()
+    cs = torch.empty((nq, nprobe), dtype=torch.float32, device="cuda")
+    pr = torch.empty((nq, nprobe), dtype=torch.int64, device="cuda")
+    flat_search(cent, nlist, q, nprobe, cs, pr)
+    ld = (nlist + 1) // 2 * 2
+    keys = torch.empty((nq, ld), dtype=torch.int64, device="cuda")
+    cnt = torch.full((nq,), nlist, dtype=torch.int64, device="cuda")
+    cs2, pr2 = torch.empty_like(cs), torch.empty_like(pr)
+    _lib.check(lib.amdrec_ivf_coarse_keys(_lib.ptr(cent), nlist, cent.stride(0), 256, _lib.ptr(q), nq, q.stride(0),
+                                          _lib.ptr(keys), ld, _lib.stream_ptr(cent.device)))
+    _lib.check(lib.amdrec_ivf_select(_lib.ptr(keys), ld, _lib.ptr(cnt), nq, nprobe, _lib.ptr(cs2), _lib.ptr(pr2),
+                                     _lib.stream_ptr(cent.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(cs, cs2)
+    assert torch.equal(pr, pr2)
+    ref = (q.double() @ cent.double().T).cpu().numpy()
+    assert np.abs(np.sort(ref, axis=1)[:, ::-1][:, :nprobe] - cs2.cpu().numpy()).max() <= cases.SCORE_ATOL
