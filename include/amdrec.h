@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMDREC_ABI_VERSION 6
+#define AMDREC_ABI_VERSION 7
 #define AMDREC_MAX_K 2048
 
 int amdrec_abi_version(void);
@@ -227,6 +227,14 @@ typedef struct {
     float hn[AMDREC_MAX_LAYERS], hb[AMDREC_MAX_LAYERS];
     float sw_cross[AMDREC_MAX_LAYERS];
     float sw_h1, sw_h2, hn_head, hb_head;
+    /* Optional second packing of the SAME fragment sets for the column-split kernel (csrc/rowowner16c.hpp; variant 16
+     * only): a workgroup of four waves owns 16 rows and the waves split each layer's output features, so that one
+     * request's 500 candidates (inference.py:241-250) spread over 32 CUs instead of 8 - results bit-identical to the
+     * 16-row kernel.  Every 16 KB chunk holds one group of four fragment sets per wave (amdrec/weights.py x3c_stream_*).
+     * Used for passes of at most cs_max_rows rows (0 = default 4096, < 0 = never); NULL -> off. */
+    const void* stream_cs;
+    int64_t chunks_cs;
+    int64_t cs_max_rows;
 } amdrec_x3_weights;
 
 typedef struct {

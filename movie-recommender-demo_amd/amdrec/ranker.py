@@ -93,6 +93,10 @@ class TransformerRanker(nn.Module):
         # end either way) and beats it from 2 users up (B = 16: 0.65 vs 0.79 ms; tools/latency_by_engine.py)
         self.x3_min_rows = 1
         self.x3_variant = 16                          # 16: rowowner16.hpp (two waves per SIMD, default: 15 % faster); 32: rowowner.hpp
+        # passes of at most this many rows take the column-split kernel (csrc/rowowner16c.hpp: 16 rows per workgroup, the
+        # waves split the output features; bit-identical results).  0 = the library's default (4096 rows = 8 requests of
+        # 500 candidates), -1 = never
+        self.x3_cs_max_rows = 0
 
     ENGINES = ("f16x3", "bf16x6", "fp32")
     SMALL_ROWS = 8192       # passes of at most this many rows run the fp32-MFMA small shapes (csrc/layers.hip)
@@ -154,6 +158,7 @@ class TransformerRanker(nn.Module):
         if self.gemm_engine not in self.ENGINES:
             raise ValueError(f"gemm_engine must be one of {self.ENGINES}")
         key = (str(device), self.fuse_attention, self.gemm_engine, int(self.x3_min_rows), int(self.x3_variant),
+               int(self.x3_cs_max_rows),
                tuple(p._version for p in self.parameters()))
         if self._packed is None or self._packed[0] != key:
             sd = self.state_dict()
@@ -162,7 +167,8 @@ class TransformerRanker(nn.Module):
                                                       self._n_num, device, fuse_attention=self.fuse_attention,
                                                       x6=self.gemm_engine == "bf16x6" or
                                                       (self.gemm_engine == "f16x3" and not x3),
-                                                      x3=x3, x3_min_rows=self.x3_min_rows, x3_variant=self.x3_variant)
+                                                      x3=x3, x3_min_rows=self.x3_min_rows, x3_variant=self.x3_variant,
+                                                      x3_cs_max_rows=self.x3_cs_max_rows)
             self._packed = (key, params, keep, tasks)
         return self._packed[1], self._packed[3]
 

@@ -34,7 +34,8 @@ class X3Weights(C.Structure):
                 ("variant", C.c_int64),
                 ("sw_ov", C.c_float * MAX_LAYERS), ("sw_1", C.c_float * MAX_LAYERS), ("sw_2", C.c_float * MAX_LAYERS),
                 ("hn", C.c_float * MAX_LAYERS), ("hb", C.c_float * MAX_LAYERS), ("sw_cross", C.c_float * MAX_LAYERS),
-                ("sw_h1", C.c_float), ("sw_h2", C.c_float), ("hn_head", C.c_float), ("hb_head", C.c_float)]
+                ("sw_h1", C.c_float), ("sw_h2", C.c_float), ("hn_head", C.c_float), ("hb_head", C.c_float),
+                ("stream_cs", _FP), ("chunks_cs", C.c_int64), ("cs_max_rows", C.c_int64)]
 
 
 class RankerParams(C.Structure):
@@ -211,14 +212,72 @@ def x3b_stream_heads(f1, f2s, tiles_per_task):
     return np.stack(out)
 
 
+def _wave_chunk(groups):
+    """One 16 KB chunk of the column-split kernel: group w (4 fragment sets) for wave w; None = a wave without work (zeros)."""
+    out = []
+    for g in groups:
+        out += g if g is not None else [np.zeros((64, 8), np.uint16)] * 4
+    assert len(out) == 16
+    return out
+
+
+def x3c_stream_gemm256(fr):
+    """Column-split kernel (csrc/rowowner16c.hpp): wave w owns output tiles 4 w .. 4 w + 3 = tile pairs 2 w, 2 w + 1; per
+    k-step two chunks (pair j of every wave)."""
+    assert fr.shape[0] == 16
+    out = []
+    for ks in range(fr.shape[1]):
+        for j in range(2):
+            out += _wave_chunk([_pair(fr, 2 * (2 * w + j), ks) for w in range(4)])
+    return np.stack(out)
+
+
+def x3c_stream_ffn(f1, f2):
+    """FFN in super-steps of four hidden steps (32 hidden units each), one per wave.  Super-step T: for i < 8 the stage-1
+    chunk {wave w: W_1 tile pair of hidden step 4 T + w at k-step i} followed by the stage-2 chunk of super-step T - 1
+    {wave w: W_2 output pair 2 w + (i & 1) at k-step 4 (T - 1) + (i >> 1)}."""
+    T = f1.shape[0] // 2
+    assert T % 4 == 0 and f2.shape[0] == 16
+    S = T // 4
+    out = []
+    for s in range(S + 1):
+        for i in range(8):
+            if s < S:
+                out += _wave_chunk([_pair(f1, 2 * (4 * s + w), i) for w in range(4)])
+            if s >= 1:
+                out += _wave_chunk([_pair(f2, 2 * (2 * w + (i & 1)), 4 * (s - 1) + (i >> 1)) for w in range(4)])
+    return np.stack(out)
+
+
+def x3c_stream_heads(f1, f2s, tiles_per_task):
+    """Heads in super-steps of four hidden steps (counted through all tasks; tiles_per_task % 4 == 0 keeps a super-step inside
+    one task).  Stage 1 as in the FFN; stage 2 of super-step s - 1 = four chunks (its k-steps, ascending) behind the stage-1
+    chunks i = 3 (two) and i = 7 (two): {wave 0: output pair 0, wave 1: pair 1, waves 2 and 3: zeros}."""
+    assert tiles_per_task % 4 == 0
+    nt = len(f2s) * tiles_per_task
+    S = nt // 4
+    out = []
+    for s in range(S + 1):
+        for i in range(8):
+            if s < S:
+                out += _wave_chunk([_pair(f1, 2 * (4 * s + w), i) for w in range(4)])
+            if s >= 1 and (i & 3) == 3:
+                first = 4 * (s - 1)
+                f2, k0 = f2s[first // tiles_per_task], first % tiles_per_task
+                for kk in (2 * (i >> 2), 2 * (i >> 2) + 1):
+                    out += _wave_chunk([_pair(f2, 0, k0 + kk), _pair(f2, 2, k0 + kk), None, None])
+    return np.stack(out)
+
+
 def pack_x3_stream(mats: Dict, variant: int = 32) -> Dict:
     """mats: float64 matrices of the chain {"ov": [L x [256][256]], "w1": [L x [d_ff][256]], "b1": [L x [d_ff]], "w2":
     [L x [256][d_ff]], "cross": [C x [256][256] (already [out][in])], "h1": [T*h1][256], "hb1": [T*h1], "h2": [T x
     [64][h1]]} -> {"stream": uint16 [n_frag][64][8], "chunks", scales and hidden bounds} for amdrec_x3_weights."""
-    assert variant in (16, 32)
-    frags, s_gemm, s_ffn, s_heads = ((x3_frags, x3_stream_gemm256, x3_stream_ffn, x3_stream_heads) if variant == 32 else
-                                     (x3b_frags, x3b_stream_gemm256, x3b_stream_ffn, x3b_stream_heads))
-    s_cross = s_gemm if variant == 32 else x3b_stream_cross
+    assert variant in (16, 32, "16cs")                  # "16cs": the 16-row fragments in the column-split kernel's order
+    frags, s_gemm, s_ffn, s_heads = {32: (x3_frags, x3_stream_gemm256, x3_stream_ffn, x3_stream_heads),
+                                     16: (x3b_frags, x3b_stream_gemm256, x3b_stream_ffn, x3b_stream_heads),
+                                     "16cs": (x3b_frags, x3c_stream_gemm256, x3c_stream_ffn, x3c_stream_heads)}[variant]
+    s_cross = x3b_stream_cross if variant == 16 else s_gemm
     parts = []
     sc = {"sw_ov": [], "sw_1": [], "sw_2": [], "hn": [], "hb": [], "sw_cross": []}
     for l in range(len(mats["ov"])):
@@ -368,7 +427,7 @@ def x3_eligible(sd: Dict, fuse_attention: bool) -> bool:
 
 def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int, device, ln_eps=1e-5,
                 fuse_attention: bool = True, x6: bool = True, x3: bool = False, x3_min_rows: int = 0,
-                x3_variant: int = 32):
+                x3_variant: int = 32, x3_cs_max_rows: int = 0):
     """state_dict-like of the reference TransformerRanker -> (RankerParams, Packed, task names).
     ``fuse_attention``: pre-multiply W_ov = W_o W_v, b_ov = W_o b_v + b_o in float64 (the seq-len-1
     attention is exactly W_o(W_v x + b_v) + b_o, transformer_ranker.py:59-88 with :358), so each
@@ -493,6 +552,12 @@ def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int
         p.x3.stream = pk.ptr(x["stream"].view(np.int16))
         p.x3.chunks = x["chunks"]
         p.x3.min_rows = int(x3_min_rows)
+        if x3_variant == 16 and x3_cs_max_rows >= 0 and p.d_ff % 128 == 0 and p.head_h1 % 128 == 0:
+            xc = pack_x3_stream(mats, "16cs")               # same planes and scales, the column-split kernel's chunk order
+            assert all(xc[k] == x[k] for k in ("sw_ov", "sw_1", "sw_2", "sw_cross", "sw_h1", "sw_h2"))
+            p.x3.stream_cs = pk.ptr(xc["stream"].view(np.int16))
+            p.x3.chunks_cs = xc["chunks"]
+        p.x3.cs_max_rows = int(x3_cs_max_rows)
         for li in range(p.n_layers):
             p.x3.sw_ov[li], p.x3.sw_1[li], p.x3.sw_2[li] = x["sw_ov"][li], x["sw_1"][li], x["sw_2"][li]
             p.x3.hn[li], p.x3.hb[li] = x["hn"][li], x["hb"][li]

@@ -3,6 +3,7 @@
 //   amdrec_ranker_x3_prefix : debugging / test entry: run the first n phases on a dense X and return the rows
 #include "rowowner.hpp"
 #include "rowowner16.hpp"
+#include "rowowner16c.hpp"
 #include "../../include/amdrec.h"
 
 using namespace amdrec;
@@ -27,8 +28,14 @@ static bool x3_eligible(const amdrec_ranker_params* p) {
     return true;
 }
 
-// n_phases < 0: the whole chain
-static int x3_build(const amdrec_ranker_params* p, int n_phases, x3::Program& G) {
+// the column-split stream (rowowner16c.hpp) is present and the architecture fits its super-steps of four hidden tiles
+static bool x3c_available(const amdrec_ranker_params* p) {
+    return p->x3.variant == 16 && p->x3.stream_cs != nullptr && p->x3.chunks_cs > 0 && p->d_ff % 128 == 0 &&
+           p->head_h1 % 128 == 0;
+}
+
+// n_phases < 0: the whole chain; cs: the column-split kernel's stream
+static int x3_build(const amdrec_ranker_params* p, int n_phases, x3::Program& G, bool cs = false) {
     memset(&G, 0, sizeof(G));
     int n = 0, o = 0;                                               // o: running offset into the parameter blob (floats)
     for (int l = 0; l < p->n_layers; ++l) {
@@ -58,14 +65,16 @@ static int x3_build(const amdrec_ranker_params* p, int n_phases, x3::Program& G)
     G.n_params = (int)p->x3.n_params;
     // chunks consumed by a prefix of the chain (the ring only needs to know where the stream ends)
     const long long per_layer = 16 + 4ll * (p->d_ff / 32);          // W_ov: 16 chunks; FFN: 64 fragment sets per hidden tile
-    const long long heads = (long long)p->n_tasks * (p->head_h1 / 32) * 40 / 16;
-    REQUIRE((long long)p->n_tasks * (p->head_h1 / 32) * 40 % 16 == 0, "x3: head stream is not a whole number of chunks");
+    // heads: 8 stage-1 + 2 stage-2 groups per hidden tile; column-split: per 4 hidden tiles 8 + 4 chunks (stage 2 half empty)
+    const long long hidden_tiles = (long long)p->n_tasks * (p->head_h1 / 32);
+    const long long heads = cs ? hidden_tiles * 3 : hidden_tiles * 40 / 16;
+    REQUIRE(cs || hidden_tiles * 40 % 16 == 0, "x3: head stream is not a whole number of chunks");
     const long long total = p->n_layers * per_layer + 16ll * p->n_cross + heads;
-    REQUIRE(total == p->x3.chunks, "x3: stream length %lld chunks does not match the architecture (%lld)",
-            (long long)p->x3.chunks, total);
+    const long long have = cs ? p->x3.chunks_cs : p->x3.chunks;
+    REQUIRE(total == have, "x3: stream length %lld chunks does not match the architecture (%lld)", have, total);
     G.n_phases = n_phases < 0 || n_phases > n ? n : n_phases;
     G.total_chunks = (int)total;
-    G.stream = reinterpret_cast<const unsigned char*>(p->x3.stream);
+    G.stream = reinterpret_cast<const unsigned char*>(cs ? p->x3.stream_cs : p->x3.stream);
     return AMDREC_OK;
 }
 
@@ -86,6 +95,26 @@ static int x3_launch(const x3::Program& G, const x3::Input& in, long long rows, 
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(x3b4::ranker_x3b_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, x3::RING_BYTES + x3::PARAM_FLOATS * 4));
         attr_done.mark();
+    }
+    if (variant == 160) {                              // column-split: 16 rows per workgroup (the caller built G on that stream)
+        static PerDeviceOnce attr_cs;
+        if (attr_cs.pending()) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(x3c::ranker_x3c_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, x3c::LDS_BYTES));
+            attr_cs.mark();
+        }
+        double w = 0;
+        for (int i = 0; i < G.n_phases; ++i) {
+            const x3::Phase& P = G.ph[i];
+            if (P.type == x3::PH_ATTN_LN || P.type == x3::PH_CROSS) w += 256.0 * 256.0;
+            else if (P.type == x3::PH_FFN_LN) w += 2.0 * 256.0 * 32.0 * P.n_steps;
+            else w += (double)P.n_tasks * (256.0 * 32.0 * P.n_steps + 64.0 * 32.0 * P.n_steps + 64.0);
+        }
+        ProfScope prof("ranker_colsplit16_x3", 2.0 * (double)rows * w, (double)rows * (1024.0 + 12.0), st);
+        hipLaunchKernelGGL(x3c::ranker_x3c_kernel, dim3((unsigned)((rows + x3c::ROWS_PER_WG - 1) / x3c::ROWS_PER_WG)),
+                           dim3(64 * x3c::WAVES), x3c::LDS_BYTES, st, G, in, rows, x_out, ld_xout, logits, ld_logits);
+        HIP_TRY(hipGetLastError());
+        return AMDREC_OK;
     }
     // 16-row variant, small passes: 64-row workgroups of four waves (one per SIMD) - a pass that fits the chip once in that
     // shape (<= 256 CUs x 64 rows) finishes in ~0.7 of the 128-row shape's time (one request's 500 rows: 0.20 against
@@ -128,8 +157,11 @@ size_t ranker_x3_scratch_bytes(long long rows) { return x3_scratch_bytes(rows); 
 int ranker_x3_run(const amdrec_ranker_params* p, const float* X, long long ldx, const float* U, const long long* rowmap,
                   long long row_base, int rowdiv, long long n_cache, long long rows, float* scratch, float* logits,
                   long long ld_logits, hipStream_t st) {
+    // one request's pass (<= 4096 rows by default): the column-split kernel, 16 rows per workgroup
+    const long long cs_rows = p->x3.cs_max_rows > 0 ? p->x3.cs_max_rows : (p->x3.cs_max_rows < 0 ? 0 : x3c::MAX_ROWS);
+    const bool cs = x3c_available(p) && rows <= cs_rows;
     x3::Program G;
-    int rc = x3_build(p, -1, G);
+    int rc = x3_build(p, -1, G, cs);
     if (rc) return rc;
     x3::Input in{};
     if (X != nullptr) {
@@ -138,7 +170,7 @@ int ranker_x3_run(const amdrec_ranker_params* p, const float* X, long long ldx, 
         in.cache = p->ad_proj_cache; in.ldc = p->ld_ad_proj_cache; in.n_cache = n_cache; in.rowmap = rowmap; in.U = U;
         in.row_base = row_base; in.rowdiv = rowdiv;
     }
-    return x3_launch(G, in, rows, scratch, nullptr, 0, logits, ld_logits, st, (int)p->x3.variant);
+    return x3_launch(G, in, rows, scratch, nullptr, 0, logits, ld_logits, st, cs ? 160 : (int)p->x3.variant);
 }
 }  // namespace amdrec
 
@@ -150,8 +182,10 @@ extern "C" int amdrec_ranker_x3_prefix(const amdrec_ranker_params* p, const floa
     if (rows <= 0) return AMDREC_OK;
     REQUIRE(ldx >= 256 && ldx % 4 == 0 && ((uintptr_t)X % 16) == 0, "bad X layout");
     REQUIRE(x_out == nullptr || (ld_out >= 256 && ld_out % 4 == 0 && ((uintptr_t)x_out % 16) == 0), "bad x_out layout");
+    const long long cs_rows = p->x3.cs_max_rows > 0 ? p->x3.cs_max_rows : (p->x3.cs_max_rows < 0 ? 0 : x3c::MAX_ROWS);
+    const bool cs = x3c_available(p) && rows <= cs_rows;
     x3::Program G;
-    int rc = x3_build(p, n_phases, G);
+    int rc = x3_build(p, n_phases, G, cs);
     if (rc) return rc;
     const bool heads = G.n_phases == 2 * p->n_layers + p->n_cross + 1;
     REQUIRE(!heads || (logits != nullptr && ld_logits >= rows), "the full chain needs a logits buffer");
@@ -161,5 +195,5 @@ extern "C" int amdrec_ranker_x3_prefix(const amdrec_ranker_params* p, const floa
     x3::Input in{};
     in.X = X; in.ldx = ldx;
     return x3_launch(G, in, rows, reinterpret_cast<float*>(workspace), x_out, ld_out, logits, ld_logits,
-                     reinterpret_cast<hipStream_t>(stream), (int)p->x3.variant);
+                     reinterpret_cast<hipStream_t>(stream), cs ? 160 : (int)p->x3.variant);
 }

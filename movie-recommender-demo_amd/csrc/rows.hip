@@ -122,8 +122,9 @@ __global__ __launch_bounds__(256) void select_topk_small_kernel(const float* log
         }
         key[j] = kk;
     }
-    for (int r = 0; r < top_k; ++r) {
-        unsigned long long m = key[0];
+    unsigned long long mine = 0ull;                            // lane r keeps winner r: the dependent loads (candidate id, the
+    for (int r = 0; r < top_k; ++r) {                          // tasks' logits) go out together after the loop, one latency
+        unsigned long long m = key[0];                         // instead of one per rank (they were 10 of the kernel's 15 us)
 #pragma unroll
         for (int j = 1; j < KPL; ++j) m = key[j] > m ? key[j] : m;
 #pragma unroll
@@ -133,15 +134,17 @@ __global__ __launch_bounds__(256) void select_topk_small_kernel(const float* log
         }
 #pragma unroll
         for (int j = 0; j < KPL; ++j) key[j] = key[j] == m ? 0ull : key[j];      // retire the winner (0 = empty)
-        if (lane == 0) {
-            const bool valid = r < k_c && m != 0ull;
-            const int slot = valid ? (int)key_pos(m) : -1;
-            out_ids[u * top_k + r] = valid ? cand_ids[u * k_c + slot] : -1;
-            if (out_slots) out_slots[u * top_k + r] = slot;
-            for (int t = 0; t < n_tasks; ++t) {
-                const float x = valid ? logits[(long long)t * ld + u * k_c + slot] : -INFINITY;
-                out_scores[((long long)t * n_users + u) * top_k + r] = 1.0f / (1.0f + expf(-x));
-            }
+        if (lane == r) mine = m;
+    }
+    if (lane < top_k) {
+        const int r = lane;
+        const bool valid = r < k_c && mine != 0ull;
+        const int slot = valid ? (int)key_pos(mine) : -1;
+        out_ids[u * top_k + r] = valid ? cand_ids[u * k_c + slot] : -1;
+        if (out_slots) out_slots[u * top_k + r] = slot;
+        for (int t = 0; t < n_tasks; ++t) {
+            const float x = valid ? logits[(long long)t * ld + u * k_c + slot] : -INFINITY;
+            out_scores[((long long)t * n_users + u) * top_k + r] = 1.0f / (1.0f + expf(-x));
         }
     }
 }

@@ -61,7 +61,8 @@ def _prefix(m, X, n_phases):
     return x_out.cpu().numpy(), logits.cpu().numpy()
 
 
-@pytest.mark.parametrize("rows", [128 * 3 + 45,            # <= 16384 rows: the 64-row workgroup shape (x3b4), ragged tail
+@pytest.mark.parametrize("rows", [128 * 3 + 45,            # <= 4096 rows: the column-split kernel (x3c, variant 16), ragged tail
+                                  4096 + 64 * 5 + 13,      # <= 16384 rows: the 64-row workgroup shape (x3b4), ragged tail
                                   16384 + 128 * 3 + 45])   # beyond: the 128-row shape (x3b), three full workgroups + a ragged one
 @pytest.mark.parametrize("cross", ["scaled", "randn"])
 def test_every_prefix_of_the_chain_matches_float64(cross, rows, accuracy):
@@ -157,3 +158,29 @@ def test_x3_degenerate_weights_zero_ffn_and_zero_cross():
         x, _ = _prefix(m, torch.from_numpy(X).cuda(), n)
         ref = truth[n - 1]
         assert np.isfinite(x).all() and (np.abs(x - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= 2e-5, n
+
+
+@pytest.mark.parametrize("rows", [500, 16 * 3 + 5, 4096, 1])
+def test_column_split_kernel_is_bit_identical_to_the_16_row_kernel(rows):
+    """csrc/rowowner16c.hpp (four waves split the output features of 16 rows) against csrc/rowowner16.hpp (a wave owns its
+    16 rows alone): the same MFMAs in the same order per output element, the same row-wise functions on the same values -
+    every prefix of the chain and the logits must be EQUAL, not close."""
+    if VARIANT != 16:
+        pytest.skip("the column-split kernel belongs to the 16-row variant")
+    from amdrec import _lib
+    m, sd, dims = _model("demo", "randn")
+    X = torch.from_numpy(_projected_rows(sd, dims, rows, seed=47)).cuda()
+    lib = _lib.load()
+    for n in list(range(1, 11)):
+        m.x3_cs_max_rows = -1
+        x_ref, l_ref = _prefix(m, X, n)
+        m.x3_cs_max_rows = 0
+        _lib.check(lib.amdrec_profile_enable(1))
+        x_cs, l_cs = _prefix(m, X, n)
+        tags = list(_lib.profile_report())
+        _lib.check(lib.amdrec_profile_enable(0))
+        assert tags == ["ranker_colsplit16_x3"], tags
+        if n < 10:
+            assert np.array_equal(x_ref, x_cs), (n, np.abs(x_ref - x_cs).max())
+        else:
+            assert np.isfinite(l_ref).all() and np.array_equal(l_ref, l_cs), np.abs(l_ref - l_cs).max()

@@ -298,3 +298,96 @@ def test_parameter_blob_layout_matches_the_kernels_offsets():
         assert blob[o + 128] == sd[f"prediction_heads.{t}.6.bias"][0]
         o += 132
     assert not blob[o:].any()
+
+
+# ---- the column-split kernel (csrc/rowowner16c.hpp): every chunk = one group per wave ------------------------------
+def test_column_split_stream_gives_every_wave_its_group_in_every_chunk():
+    """Host emulation of the kernel's loops, wave by wave: chunk c = 16 fragment sets, wave w multiplies sets 4 w .. 4 w + 3.
+    gemm256: wave w accumulates output tiles 4 w .. 4 w + 3; FFN / heads: super-steps of four hidden steps, one per wave, stage
+    2 of super-step T - 1 interleaved behind stage 1 of T; heads' stage 2 on waves 0, 1 (zeros for 2, 3)."""
+    user, ad, nnum, sd, _ = cases.ranker_case("demo", "scaled")
+    p, pk, tasks = weights.pack_ranker(sd, list(user), list(ad), nnum, "cpu", x3=True, x3_variant=16)
+    assert p.x3.chunks_cs == 3 * (16 + 128) + 3 * 16 + 3 * 8 * 3 and p.x3.cs_max_rows == 0
+    stream = [t for t in pk._keep if t.data_ptr() == p.x3.stream_cs][0].numpy().view(np.uint16).reshape(-1, 64, 8)
+    assert stream.shape[0] == p.x3.chunks_cs * 16
+    st = Stream(stream)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((16, 256))
+    f64 = lambda k: np.asarray(sd[k], dtype=F)     # noqa: E731
+    rows = lambda acc: np.concatenate([t.T for t in acc], axis=1)     # noqa: E731
+
+    def chunk(bs, accs, t0s):
+        """one chunk: wave w's group against its B fragment bs[w] into accs[w][t0s[w]], [t0s[w] + 1] (None: no work)"""
+        a = st.read(16)
+        for w in range(4):
+            if accs[w] is None:
+                assert not a[4 * w:4 * w + 4].any()          # zero fragments for a wave without work
+                continue
+            accs[w][t0s[w]] += _mfma16(a[4 * w] + a[4 * w + 1], bs[w])
+            accs[w][t0s[w] + 1] += _mfma16(a[4 * w + 2] + a[4 * w + 3], bs[w])
+
+    def gemm256():
+        acc = [np.zeros((16, 16), F) for _ in range(16)]
+        xb = _b16(x)
+        for ks in range(8):
+            for j in range(2):
+                chunk([xb[ks]] * 4, [acc] * 4, [4 * w + 2 * j for w in range(4)])
+        return rows(acc)
+
+    for l in range(3):
+        pre = f"transformer_layers.{l}"
+        wov = (f64(pre + ".self_attention.W_o.weight") @ f64(pre + ".self_attention.W_v.weight")).astype(np.float32).astype(F)
+        got = gemm256() / p.x3.sw_ov[l]
+        assert np.abs(got - x @ wov.T).max() <= 1e-5 * np.abs(x @ wov.T).max(), ("ov", l)
+        w1, b1, w2 = f64(pre + ".feed_forward.fc1.weight"), f64(pre + ".feed_forward.fc1.bias"), f64(pre + ".feed_forward.fc2.weight")
+        acc2 = [np.zeros((16, 16), F) for _ in range(16)]
+        xb = _b16(x)
+        hid = {}
+        for T in range(9):
+            a1 = [[np.zeros((16, 16), F), np.zeros((16, 16), F)] for _ in range(4)]
+            for i in range(8):
+                if T < 8:
+                    chunk([xb[i]] * 4, a1, [0] * 4)
+                if T >= 1:
+                    chunk([hid[T - 1][i >> 1]] * 4, [acc2] * 4, [4 * w + 2 * (i & 1) for w in range(4)])
+            if T < 8:
+                hid[T] = [_hidden16(np.maximum(rows(a1[w]) / p.x3.sw_1[l] + b1[32 * (4 * T + w):32 * (4 * T + w) + 32][None, :], 0))
+                          for w in range(4)]
+        got = rows(acc2) / p.x3.sw_2[l]
+        ref = np.maximum(x @ w1.T + b1, 0) @ w2.T
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), ("ffn", l)
+    for c in range(3):
+        wc = f64(f"feature_interaction.cross_weights.{c}")
+        got = gemm256() / p.x3.sw_cross[c]
+        assert np.abs(got - x @ wc).max() <= 1e-5 * np.abs(x @ wc).max(), ("cross", c)
+    xb = _b16(x)
+    Tt, S = 8, 8 * len(tasks) // 4
+    acc2 = {t: [np.zeros((16, 16), F) for _ in range(4)] for t in tasks}
+    hid = {}
+    for ss in range(S + 1):
+        a1 = [[np.zeros((16, 16), F), np.zeros((16, 16), F)] for _ in range(4)]
+        for i in range(8):
+            if ss < S:
+                chunk([xb[i]] * 4, a1, [0] * 4)
+            if ss >= 1 and (i & 3) == 3:
+                task = tasks[4 * (ss - 1) // Tt]
+                for kk in (2 * (i >> 2), 2 * (i >> 2) + 1):
+                    chunk([hid[ss - 1][kk]] * 4, [acc2[task], acc2[task], None, None], [0, 2, 0, 0])
+        if ss < S:
+            hid[ss] = []
+            for w in range(4):
+                tt = 4 * ss + w
+                b1 = f64(f"prediction_heads.{tasks[tt // Tt]}.0.bias")
+                hid[ss].append(_hidden16(np.maximum(rows(a1[w]) / p.x3.sw_h1 + b1[32 * (tt % Tt):32 * (tt % Tt) + 32][None, :], 0)))
+    for t in tasks:
+        w1, b1, w2 = f64(f"prediction_heads.{t}.0.weight"), f64(f"prediction_heads.{t}.0.bias"), f64(f"prediction_heads.{t}.3.weight")
+        got = rows(acc2[t]) / p.x3.sw_h2
+        ref = np.maximum(x @ w1.T + b1, 0) @ w2.T
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), ("head", t)
+    assert st.pos == stream.shape[0]
+    # the 16-row kernel's stream holds the same fragment sets (the column-split one adds only zero sets)
+    base = [t for t in pk._keep if t.data_ptr() == p.x3.stream][0].numpy().view(np.uint16).reshape(-1, 64 * 8)
+    nz = stream.reshape(-1, 64 * 8)
+    nz = nz[nz.any(axis=1)]
+    key = lambda a: np.sort(np.ascontiguousarray(a).view([("", a.dtype)] * a.shape[1]).ravel())    # noqa: E731
+    assert (key(base[base.any(axis=1)]) == key(nz)).all()
