@@ -447,9 +447,29 @@ __device__ __forceinline__ void phase_heads(Ring& ring, f16x8 (&cur)[4], const E
     stage2_done();
 }
 
-__global__ __launch_bounds__(64 * WAVES) void ranker_x3c_kernel(Program G, Input in, long long rows, float* x_out,
+// PREFETCH workgroups.  The kernel's bound is the latency-limited rate of ONE workgroup's 48 KB of DMA in flight, so it matters
+// where the stream comes from: 118 us per launch when the 8.8 MB sit in the memory-side cache (back-to-back launches),
+// 165 us in the serving pipeline, where the search's 1 GB corpus scan has just pushed them out to HBM
+// (profiles/r03_trace_b1_colsplit.log).  The pass occupies a few dozen of the 256 CUs, so the launch carries PREFETCH_WGS
+// extra workgroups that do nothing but read one slice of the stream each (9 x 16 B per thread, all in flight at once) and
+// exit: the stream is on its way into the cache hierarchy within the first microseconds of the kernel.
+constexpr int PREFETCH_WGS = 64;
+
+__global__ __launch_bounds__(64 * WAVES) void ranker_x3c_kernel(Program G, Input in, long long rows, int n_row_wgs, float* x_out,
                                                                  long long ld_xout, float* logits, long long ld_logits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_pre = (int)gridDim.x - n_row_wgs;                 // the FIRST workgroups of the grid: dispatched first even
+    if ((int)blockIdx.x < n_pre) {                                // when the row workgroups fill every CU (one per CU: LDS)
+        const int j = (int)blockIdx.x;
+        const long long n16 = (long long)G.total_chunks * (CHUNK_BYTES / 16);          // 16-byte words of the stream
+        const long long per = (n16 + n_pre - 1) / n_pre;
+        const f32x4* src = reinterpret_cast<const f32x4*>(G.stream);
+        float sink = 0.f;
+        for (long long i = j * per + threadIdx.x; i < (j + 1) * per && i < n16; i += 64 * WAVES) sink += src[i][0];
+        asm volatile("" ::"v"(sink));
+        return;
+    }
+    const int wg = (int)blockIdx.x - n_pre;                       // row workgroup
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, q = lane & 15;
@@ -464,7 +484,7 @@ __global__ __launch_bounds__(64 * WAVES) void ranker_x3c_kernel(Program G, Input
     E.ex = pbase + PARAM_FLOATS * 4 + lane * 16;
     E.hid = pbase + PARAM_FLOATS * 4 + EX_BYTES + lane * 16;
 
-    const long long row = (long long)blockIdx.x * ROWS_PER_WG + q;
+    const long long row = (long long)wg * ROWS_PER_WG + q;
     const bool row_ok = row < rows;
     const long long rowc = row_ok ? row : rows - 1;
     f32x4 x[16];                                                  // every wave loads the workgroup's 16 rows
@@ -503,7 +523,7 @@ __global__ __launch_bounds__(64 * WAVES) void ranker_x3c_kernel(Program G, Input
     if (x_out != nullptr && row_ok && wave == 0) store_rows(x, x_out + row * ld_xout, g);
     ring.drain();
     if ((CDBG & 16) && lane == 0) {           // diagnostic build: s_memtime ticks (100 MHz) into the unused tail of the logits buffer
-        float* dbg = logits + 3 * ld_logits + ((long long)blockIdx.x * WAVES + wave) * 4;
+        float* dbg = logits + 3 * ld_logits + ((long long)wg * WAVES + wave) * 4;
         dbg[0] = (float)(__builtin_amdgcn_s_memtime() - t_begin);
         dbg[1] = (float)ring.t_wait;
         dbg[2] = (float)ring.t_bar;
