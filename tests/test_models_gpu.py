@@ -122,9 +122,12 @@ def test_ranker_unfused_attention_matches_too():
         assert ok, (t, err)
 
 
-def test_ranker_score_candidates_broadcast_and_gather():
-    m, sd, (user, ad, nnum), _ = _ranker("ragged", "scaled")
-    U, k, N = 7, 500, 5000
+@pytest.mark.parametrize("name,U,k", [("ragged", 7, 500), ("demo", 1, 500), ("demo", 16, 100), ("demo", 17, 100)])
+def test_ranker_score_candidates_broadcast_and_gather(name, U, k):
+    """The hoisted form: user half of the projection once per user (<= 16 users: csrc/layers.hip user_proj_small_kernel,
+    beyond: the tile GEMM), candidate half gathered from the resident ad table."""
+    m, sd, (user, ad, nnum), _ = _ranker(name, "scaled")
+    N = 5000
     uc, un = synth.user_batch(user, nnum, U, seed=9)
     table = synth.ad_features(ad, N, seed=10)
     rng = np.random.default_rng(11)
