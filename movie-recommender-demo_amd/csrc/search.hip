@@ -1213,6 +1213,233 @@ __global__ __launch_bounds__(512) void finalize_sort_kernel(const unsigned long 
     write_result(keys, m, k, q, outD, outI, pos_offset);
 }
 
+// Small batches (<= SPLIT_MAX_NQ queries), round 3: select -> prune -> re-score -> sort -> certificate in ONE launch of
+// gridDim.x workgroups per query (the three kernels above cost 38 us at one query: 12.5 + 8 + 17, each of the small ones
+// mostly launch-to-drain latency).  Every workgroup of a query repeats the select + prune on the query's candidates (the same
+// deterministic result in each: redundant, but in parallel), re-scores the survivors whose corpus position falls to it
+// (pos % gridDim.x: a share that does not depend on the order in which a block's threads compacted the survivors), appends
+// the exact keys to the query's list in the workspace, and takes a ticket; the workgroup that draws the LAST ticket (agent-scope
+// release / acquire around it, as in fixup_kernel) sorts the list - sort_desc_runs for <= 1024 survivors -, certifies and
+// writes the result.  Same per-row re-score arithmetic, same prune, same certificate as the kernels above.
+__global__ __launch_bounds__(512) void finalize_fused_kernel(const unsigned long long* cand, long long cstride, const int* segcnt,
+                                                             int nseg, int seg_cap, const int* ocnt, int cap, int k,
+                                                             long long nrows, const float* tau, const float* max_norm,
+                                                             const float* X, long long ldx, int d, const float* Q, long long ldq,
+                                                             int* fail, float* outD, long long* outI, long long pos_offset,
+                                                             unsigned long long* exact, int* fcount, int* fticket) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [cap] then qv[d]
+    float* qv = reinterpret_cast<float*>(keys + cap);
+    __shared__ int hist[2048];
+    __shared__ int scratch[514];
+    __shared__ float red[16];
+    __shared__ int m_sh, own_sh, base_sh, last_sh;
+    __shared__ int seg_n[256], tot_sh, lost_sh;
+    constexpr int PER = CAND_CAP / 512;
+    constexpr int OVP = 4;
+    const int q = blockIdx.y, nq = gridDim.y, s = blockIdx.x, S = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int need = (int)(nrows < k ? nrows : k);
+    auto give_up = [&]() {                                      // every workgroup of the query reaches the same verdict: one reports
+        if (tid == 0 && s == 0) {
+            fail[q] = 1;
+            atomicAdd(&fail[nq], 1);
+        }
+    };
+    // the candidate slots are requested before the segment counts that say which of them are valid have arrived (one
+    // global round trip instead of two); validity is applied below
+    const unsigned long long* blk = cand + (long long)q * cstride;
+    const int nslots = nseg * seg_cap;
+    unsigned long long mine[PER + OVP];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int s_ = tid + 512 * j;
+        mine[j] = s_ < nslots ? blk[s_] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < OVP; ++j) mine[PER + j] = blk[CAND_CAP + tid + 512 * j];
+    if (tid == 0) { tot_sh = 0; lost_sh = 0; }
+    __syncthreads();
+    int sv = 0, lost = 0;
+    if (tid < nseg) {
+        const int v = segcnt[(long long)q * nseg + tid];
+        sv = v < seg_cap ? v : seg_cap;
+        lost = v - sv;
+        seg_n[tid] = sv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sv += __shfl_xor(sv, o, 64);
+        lost += __shfl_xor(lost, o, 64);
+    }
+    if (lane == 0 && w * 64 < nseg) {
+        atomicAdd(&tot_sh, sv);
+        if (lost) atomicAdd(&lost_sh, lost);
+    }
+    const int oc = ocnt[q];
+    __syncthreads();
+    const int c = tot_sh + oc;
+    if (lost_sh != oc || oc > 512 * OVP || c < need || c > cap) { give_up(); return; }
+    float ss = 0.f, ds = 0.f;
+    for (int i = tid; i < d; i += 512) {
+        const float v = Q[(long long)q * ldq + i];
+        qv[i] = v;
+        ss += v * v;
+        const uint32_t u = __float_as_uint(v);                    // the same rounding as bf16_rows_kernel applied to the query
+        const float dv = v - __uint_as_float(((u + 0x7fffu + ((u >> 16) & 1u)) >> 16) << 16);
+        ds += dv * dv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ss += __shfl_xor(ss, o, 64);
+        ds += __shfl_xor(ds, o, 64);
+    }
+    if (lane == 0) { red[w] = ss; red[8 + w] = ds; }
+    if (tid == 0) { m_sh = 0; own_sh = 0; }
+    const int seg_shift = (nseg & (nseg - 1)) == 0 ? 31 - __builtin_clz((unsigned)nseg) : -1;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int s_ = tid + 512 * j;
+        bool ok = false;
+        if (s_ < nslots) {
+            const int slot = seg_shift >= 0 ? s_ >> seg_shift : s_ / nseg;
+            ok = slot < seg_n[s_ - slot * nseg];
+        }
+        if (!ok) mine[j] = 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < OVP; ++j)
+        if (tid + 512 * j >= oc) mine[PER + j] = 0ull;
+    __syncthreads();
+    float qn = 0.f, dqn = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { qn += red[i]; dqn += red[8 + i]; }
+    const float eps = eps_bound(sqrtf(qn), sqrtf(dqn) * 1.0001f, max_norm[0], max_norm[1], d);
+    if (!(eps < INFINITY)) { give_up(); return; }
+    if (need == 0) {
+        if (s == 0) write_result(keys, 0, k, q, outD, outI, pos_offset);
+        return;
+    }
+    // a_k to its top 22 bits (two radix passes): the remaining 10 bits cleared give a value <= a_k in the orderable image,
+    // i.e. a slightly lower cut - a superset of the survivors of the exact a_k (a relative 2^-13 of the score: no
+    // measurable number of extra survivors), never a missing one
+    uint32_t prefix = 0u, pmask = 0u;
+    int rr = need;
+    const int shifts[2] = {21, 10};
+    const int nbits[2] = {11, 11};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = tid; i < 2048; i += 512) hist[i] = 0;
+        __syncthreads();
+        const uint32_t bm = (1u << nbits[pass]) - 1u;
+#pragma unroll
+        for (int j = 0; j < PER + OVP; ++j) {
+            const uint32_t u = (uint32_t)(mine[j] >> 32);
+            if (mine[j] != 0ull && (u & pmask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & bm], 1);
+        }
+        __syncthreads();
+        const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);
+        prefix |= (uint32_t)bin << shifts[pass];
+        pmask |= bm << shifts[pass];
+    }
+    // prune (as in finalize_mixed_kernel); this workgroup keeps the survivors at positions pos % S == s
+    const float cut = f32_from_orderable(prefix) - 2.f * eps;
+    int n_surv = 0;
+#pragma unroll
+    for (int j = 0; j < PER + OVP; ++j)
+        if (mine[j] != 0ull && key_score(mine[j]) >= cut) {
+            ++n_surv;
+            if ((int)(key_pos(mine[j]) % (uint32_t)S) == s) keys[atomicAdd(&own_sh, 1)] = mine[j];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_surv += __shfl_xor(n_surv, o, 64);
+    if (lane == 0 && n_surv) atomicAdd(&m_sh, n_surv);
+    __syncthreads();
+    const int m = m_sh, own = own_sh;                         // need <= m <= c
+    // fp32 re-score of the own share, one wave per candidate, 8 in flight per wave (finalize_mixed_kernel's arithmetic)
+    const int d4 = d >> 2;
+    constexpr int RU = 8;
+    for (int i0 = w; i0 < own; i0 += 8 * RU) {
+        float a[RU];
+        uint32_t pos[RU];
+        const f32x4* xr[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int i = i0 + 8 * u;
+            a[u] = 0.f;
+            pos[u] = key_pos(keys[i < own ? i : i0]);
+            xr[u] = reinterpret_cast<const f32x4*>(X + (long long)pos[u] * ldx);
+        }
+        for (int cc = lane; cc < d4; cc += 64) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * cc]);
+            f32x4 x[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) x[u] = xr[u][cc];
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+                a[u] = __builtin_fmaf(x[u][3], y[3], __builtin_fmaf(x[u][2], y[2], __builtin_fmaf(x[u][1], y[1],
+                                      __builtin_fmaf(x[u][0], y[0], a[u]))));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // keys[i] of this round were read (pos) before they are rewritten
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            float v = a[u];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int i = i0 + 8 * u;
+            if (lane == 0 && i < own) keys[i] = (v == v) ? make_key(v, pos[u]) : 0ull;   // NaN re-score: ranks last (key 0)
+        }
+    }
+    __syncthreads();
+    if (tid == 0) base_sh = __hip_atomic_fetch_add(&fcount[q], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    unsigned long long* list = exact + (long long)q * cap;
+    for (int i = tid; i < own; i += 512) list[base_sh + i] = keys[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's stores are out
+    __syncthreads();                                           // ... every wave's
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(&fticket[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_sh = t == S - 1;
+        if (t == S - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!last_sh) return;                                      // block-uniform
+    // the query's last workgroup: all m exact keys are in the list (NaN re-scores as key 0: they sort last, as before)
+    if (m <= 1024) {
+        for (int i = tid; i < 1024; i += 512) keys[i] = i < m ? list[i] : 0ull;
+        __syncthreads();
+        // zero keys (NaN re-scores) are not placed by the run sort: clear the destination's tail first
+        for (int i = tid; i < 1024; i += 512) keys[1024 + i] = 0ull;
+        __syncthreads();
+        sort_desc_runs(keys, keys + 1024, m);
+        const unsigned long long* sorted = keys + 1024;
+        const unsigned long long kth = sorted[need - 1];
+        const bool all_rows = (long long)c >= nrows;
+        if (!all_rows && !(kth != 0ull && key_score(kth) >= tau[q] + eps)) {
+            if (tid == 0) { fail[q] = 1; atomicAdd(&fail[nq], 1); }
+            return;
+        }
+        write_result(sorted, m, k, q, outD, outI, pos_offset);
+        return;
+    }
+    int P2 = 2;
+    while (P2 < m) P2 <<= 1;
+    for (int i = tid; i < P2; i += 512) keys[i] = i < m ? list[i] : 0ull;
+    __syncthreads();
+    bitonic_desc(keys, P2);
+    const unsigned long long kth = keys[need - 1];
+    const bool all_rows = (long long)c >= nrows;
+    if (!all_rows && !(kth != 0ull && key_score(kth) >= tau[q] + eps)) {
+        if (tid == 0) { fail[q] = 1; atomicAdd(&fail[nq], 1); }
+        return;
+    }
+    write_result(keys, m, k, q, outD, outI, pos_offset);
+}
+
 __global__ void fill_f32_kernel(float* p, long long n, float v) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1224,7 +1451,7 @@ struct SearchPlan {
     long long gstride;       // rows between sample blocks
     int rank;                // r
     int nslices;             // fix-up slices
-    size_t off_tau, off_cnt, off_ocnt, off_ticket, off_fail, off_segcnt, off_cand, off_sample, off_fix, off_q16, off_m, off_eps, bytes;
+    size_t off_tau, off_cnt, off_ocnt, off_ticket, off_fcount, off_fticket, off_fail, off_segcnt, off_cand, off_sample, off_fix, off_q16, off_m, off_eps, off_exact, bytes;
 };
 
 // dim16 > 0: the mixed-precision search, which also keeps a bf16 copy of the queries in the workspace
@@ -1269,6 +1496,8 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
     pl.off_cnt = o;    o = align_up(o + (size_t)nq * 4, 256);                   // cnt | ocnt | ticket | fail: cleared together
     pl.off_ocnt = o;   o = align_up(o + (size_t)nq * 4, 256);
     pl.off_ticket = o; o = align_up(o + (size_t)nq * 4, 256);                   // fix-up: slices finished per query
+    pl.off_fcount = o; o = align_up(o + (size_t)nq * 4, 256);                   // fused finalize (small batches): exact keys appended,
+    pl.off_fticket = o; o = align_up(o + (size_t)nq * 4, 256);                  // blocks finished per query
     pl.off_fail = o;   o = align_up(o + (size_t)(nq + 1) * 4, 256);
     pl.off_segcnt = o; o = align_up(o + (size_t)(dim16 ? nq : 0) * 256 * 4, 256);  // streaming pass: hits per (query, segment)
     pl.off_cand = o;   o = align_up(o + (size_t)nq * CAND_CAP * 8 * (dim16 ? 2 : 1), 256);   // mixed: + overflow block
@@ -1277,6 +1506,7 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
     pl.off_q16 = o;    o = align_up(o + (size_t)nq * (size_t)dim16 * 2, 256);
     pl.off_m = o;      o = align_up(o + (size_t)(dim16 ? nq : 0) * 8, 256);      // split finalize: survivors | candidates per query, eps per query
     pl.off_eps = o;    o = align_up(o + (size_t)(dim16 ? nq : 0) * 4, 256);
+    pl.off_exact = o;  o = align_up(o + (size_t)(dim16 && nq <= SPLIT_MAX_NQ ? nq : 0) * CAND_CAP * 8, 256);   // fused finalize: re-scored keys
     pl.bytes = o;
     return 0;
 }
@@ -1543,6 +1773,8 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_sort_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_fused_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
         attr_done.mark();
@@ -1553,21 +1785,14 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     {
         ProfScope prof("search_finalize_mixed", 0.0, 0.0, st);
         if (nq <= SPLIT_MAX_NQ) {
-            int* m_q = reinterpret_cast<int*>(ws + pl.off_m);
-            float* eps_q = reinterpret_cast<float*>(ws + pl.off_eps);
-            int slices = (int)(1024 / nq);                          // ~1000 re-score blocks in all
-            slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
-            int* c_q = m_q + nq;
-            hipLaunchKernelGGL(finalize_mixed_kernel<true>, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, CSTRIDE, segcnt, nseg,
-                               seg_cap, (const int*)ocnt, CAND_CAP, k, (long long)nrows, tau, max_norm, corpus,
-                               (long long)ld_corpus, dim, queries, (long long)ld_queries, fail, out_scores,
-                               (long long*)out_pos, (long long)pos_offset, m_q, eps_q, c_q);
-            hipLaunchKernelGGL(finalize_rescore_kernel, dim3((unsigned)slices, (unsigned)nq), dim3(256), 0, st, cand, CSTRIDE,
-                               (const int*)m_q, corpus, (long long)ld_corpus, dim, queries, (long long)ld_queries);
-            hipLaunchKernelGGL(finalize_sort_kernel, dim3((unsigned)nq), dim3(512), CAND_CAP * 8, st,
-                               (const unsigned long long*)cand, (const int*)c_q, CSTRIDE, k, (long long)nrows, tau,
-                               (const int*)m_q, (const float*)eps_q, fail, out_scores, (long long*)out_pos,
-                               (long long)pos_offset);
+            int slices = (int)(512 / nq);                           // ~512 workgroups in all: the chip once
+            slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
+            hipLaunchKernelGGL(finalize_fused_kernel, dim3((unsigned)slices, (unsigned)nq), dim3(512), fin_lds, st,
+                               (const unsigned long long*)cand, CSTRIDE, segcnt, nseg, seg_cap, (const int*)ocnt, CAND_CAP, k,
+                               (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries,
+                               (long long)ld_queries, fail, out_scores, (long long*)out_pos, (long long)pos_offset,
+                               reinterpret_cast<unsigned long long*>(ws + pl.off_exact),
+                               reinterpret_cast<int*>(ws + pl.off_fcount), reinterpret_cast<int*>(ws + pl.off_fticket));
         } else {
             hipLaunchKernelGGL(finalize_mixed_kernel<false>, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, CSTRIDE, segcnt, nseg,
                                seg_cap, (const int*)ocnt, CAND_CAP, k, (long long)nrows, tau, max_norm, corpus,

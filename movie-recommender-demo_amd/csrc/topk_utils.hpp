@@ -76,6 +76,67 @@ __device__ inline void bitonic_desc(unsigned long long* buf, int P) {
     }
 }
 
+// Descending sort of m <= 1024 keys in LDS by a 512-thread block, keys UNIQUE and non-zero (0 = padding): `src`[0 .. m) ->
+// `dst`[0 .. m) (two different arrays of >= 1024 keys; `src` is overwritten).  Each of the 8 waves sorts a run of 128 keys
+// in registers (two per lane, a 28-stage bitonic network on shuffles), the runs go back to `src`, and every key finds its
+// final position as its index in its own run + the number of larger keys in each other run (an 8-step binary search per
+// run: the runs are sorted and the keys unique).  ~4 us against ~17 for the all-LDS bitonic network of the same size (66
+// stages, most of them behind a block barrier) - the single-query search's finalize was the sort.
+__device__ inline void sort_desc_runs(unsigned long long* src, unsigned long long* dst, int m) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned long long key[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = 128 * w + 64 * r + lane;
+        key[r] = i < m ? src[i] : 0ull;
+    }
+    __syncthreads();                                        // every key is in registers: `src` may be overwritten
+#pragma unroll
+    for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) {                                   // k == 128: the partner is the lane's other register; descending
+                const unsigned long long a = key[0], b = key[1];
+                key[0] = a > b ? a : b;
+                key[1] = a > b ? b : a;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int i = 64 * r + lane;
+                    const unsigned long long other = __shfl_xor(key[r], j, 64);
+                    const bool lower = (lane & j) == 0;          // i < partner
+                    const bool desc = (i & k) == 0;              // this k-block ends descending
+                    const bool take_max = lower == desc;
+                    const bool other_greater = other > key[r];
+                    key[r] = (take_max == other_greater) ? other : key[r];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) src[128 * w + 64 * r + lane] = key[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (key[r] == 0ull) continue;
+        int rank = 64 * r + lane;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            if (v == w) continue;
+            const unsigned long long* run = src + 128 * v;
+            int lo = 0, hi = 128;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {                 // keys of the run greater than mine: 0 .. 128 (zeros are smaller than any key)
+                const int mid = (lo + hi) >> 1;
+                if (lo < hi && run[mid] > key[r]) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        dst[rank] = key[r];
+    }
+    __syncthreads();
+}
+
 __device__ inline void write_result(const unsigned long long* buf, int have, int k, long long q, float* outD,
                                     long long* outI, long long pos_offset) {
     for (int i = threadIdx.x; i < k; i += blockDim.x) {

@@ -72,6 +72,34 @@ __device__ __forceinline__ void tower_chunk(const float* w0, const float* w1, co
     }
 }
 
+// L2 normalisation of the last layer's rows (x / max(||x||, 1e-12), F.normalize) and the store: wave w takes rows 2 w, 2 w + 1,
+// a lane 16 B at a time
+__device__ __forceinline__ void normalize_rows_out(const lds_f32* fin, int LD, int nout, long long row0, const TowerSmallArgs& a,
+                                                   int wave, int lane) {
+#pragma unroll 1
+    for (int rr = 0; rr < TS_ROWS / TS_WAVES; ++rr) {
+        const int r = (TS_ROWS / TS_WAVES) * wave + rr;
+        const lds_f32* xr = fin + r * LD;
+        float ss = 0.f;
+        for (int c = 4 * lane; c < nout; c += 256) {
+            const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        if (row0 + r < a.rows) {
+            float* o = a.out + (row0 + r) * a.ld_out;
+            for (int c = 4 * lane; c < nout; c += 256) {
+                f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] / nrm;
+                *reinterpret_cast<f32x4*>(o + c) = v;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64 * TS_WAVES) void tower_small_kernel(TowerSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) float act[];         // [2][TS_ROWS][ld_act]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -128,31 +156,129 @@ __global__ __launch_bounds__(64 * TS_WAVES) void tower_small_kernel(TowerSmallAr
         }
         __syncthreads();
     }
-    // L2 normalisation of the last layer's rows: wave w takes rows 2 w, 2 w + 1, a lane 16 B at a time
-    const lds_f32* fin = buf(a.n_layers);
-    const int nout = a.dims[a.n_layers];
-#pragma unroll 1
-    for (int rr = 0; rr < TS_ROWS / TS_WAVES; ++rr) {
-        const int r = (TS_ROWS / TS_WAVES) * wave + rr;
-        const lds_f32* xr = fin + r * LD;
-        float ss = 0.f;
-        for (int c = 4 * lane; c < nout; c += 256) {
-            const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
-            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-        }
+    normalize_rows_out(buf(a.n_layers), LD, a.dims[a.n_layers], row0, a, wave, lane);
+}
+
+// ---- the same tower as ONE software pipeline, for three-layer towers whose widths are multiples of 256 / 128 ------------------
+// In the kernel above every (layer, tile pair, chunk) starts with its own round of weight loads: five exposed load latencies
+// for the reference's user tower (109 -> 512 -> 256 -> 256) - 41 us for 1 MB of weights, 25 GB/s.  The weights do not depend
+// on the activations, so here the whole tower is a compile-time list of UNITS (one tile pair x 128 k = 16 loads of 16 B per
+// lane) and unit u + 1's loads go out before unit u's MFMAs, across turn and layer boundaries (two register buffers of 64);
+// the biases are loaded once, ahead of everything.  Loads, counted waits and the registers they release are inline asm as in
+// tower_chunk; between the input gather and the final store the compiler issues no vector-memory instruction of its own, so
+// the counts hold.  K0 = layer 0's K padded to 128, D1..D3 = the layer widths (pairs of tiles per layer: a multiple of 8).
+template <int K0, int D1, int D2, int D3>
+struct TowerPipe {
+    static constexpr int T0 = D1 / 256, T1 = D2 / 256, T2 = D3 / 256;          // turns per wave (pairs / 8)
+    static constexpr int C0 = K0 / 128, C1 = D1 / 128, C2 = D2 / 128;          // 128-k chunks per turn
+    static constexpr int U0 = T0 * C0, U1 = T1 * C1, U2 = T2 * C2, NU = U0 + U1 + U2;
+    static constexpr int NB = T0 + T1 + T2;                                    // bias pairs per wave
+    static constexpr int layer(int u) { return u < U0 ? 0 : (u < U0 + U1 ? 1 : 2); }
+    static constexpr int local(int u) { return u < U0 ? u : (u < U0 + U1 ? u - U0 : u - U0 - U1); }
+    static constexpr int chunks(int l) { return l == 0 ? C0 : (l == 1 ? C1 : C2); }
+    static constexpr int turn(int u) { return local(u) / chunks(layer(u)); }
+    static constexpr int chunk(int u) { return local(u) % chunks(layer(u)); }
+    static constexpr int bias_slot(int u) { return (layer(u) == 0 ? 0 : (layer(u) == 1 ? T0 : T0 + T1)) + turn(u); }
+
+    const TowerSmallArgs& a;
+    lds_f32* act3;
+    int LD, wave, n, g;
+    f32x4 A0[2][8], A1[2][8];
+    f32x4 B0[NB], B1[NB];
+    f32x4 acc0, acc1;
+
+    __device__ __forceinline__ lds_f32* buf(int i) const { return act3 + (i & 1) * (TS_ROWS * LD); }
+    template <int U>
+    __device__ __forceinline__ int tile() const { return 2 * (wave + TS_WAVES * turn(U)); }
+
+    template <int U>
+    __device__ __forceinline__ void issue() {
+        constexpr int L = layer(U), P = U & 1;
+        const float* w0 = a.w[L] + (long long)(16 * tile<U>() + n) * a.ldw[L] + 4 * g + 128 * chunk(U);
+        const float* w1 = w0 + 16ll * a.ldw[L];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-        if (row0 + r < a.rows) {
-            float* o = a.out + (row0 + r) * a.ld_out;
-            for (int c = 4 * lane; c < nout; c += 256) {
-                f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] / nrm;
-                *reinterpret_cast<f32x4*>(o + c) = v;
-            }
+        for (int i = 0; i < 8; ++i) {
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(A0[P][i]) : "v"(w0), "n"(64 * i));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(A1[P][i]) : "v"(w1), "n"(64 * i));
         }
     }
+    template <int S>
+    __device__ __forceinline__ void issue_bias() {
+        if constexpr (S < NB) {
+            constexpr int L = S < T0 ? 0 : (S < T0 + T1 ? 1 : 2);
+            constexpr int T = S - (L == 0 ? 0 : (L == 1 ? T0 : T0 + T1));
+            const float* b = a.b[L] + 16 * (2 * (wave + TS_WAVES * T)) + 4 * g;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(B0[S]) : "v"(b));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(B1[S]) : "v"(b));
+            issue_bias<S + 1>();
+        }
+    }
+    template <int S>
+    __device__ __forceinline__ void bias_landed() {                            // behind the first counted wait (loads return in order)
+        if constexpr (S < NB) {
+            asm volatile("" : "+v"(B0[S]), "+v"(B1[S]));
+            bias_landed<S + 1>();
+        }
+    }
+    template <int U>
+    __device__ __forceinline__ void unit() {
+        constexpr int L = layer(U), P = U & 1, C = chunk(U);
+        constexpr bool more = U + 1 < NU;
+        if constexpr (more) issue<U + 1>();
+        if constexpr (C == 0 && turn(U) == 0) {                                // the layer's input (gather / previous layer) is complete;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // not __syncthreads(): its vmcnt(0) would drain the
+            __builtin_amdgcn_s_barrier();                                      // weight loads in flight
+        }
+        if constexpr (C == 0) { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0; }
+        const lds_f32* src = buf(L) + n * LD + 4 * g + 128 * C;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(src + 16 * i);
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(A0[P][i]), "+v"(A1[P][i]) : "n"(2 * (7 - i) + (more ? 16 : 0)));
+            if constexpr (U == 0) { if (i == 0) bias_landed<0>(); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[P][i][e], bv[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[P][i][e], bv[e], acc1, 0, 0, 0);
+            }
+        }
+        if constexpr (C == chunks(L) - 1) {                                    // the pair is complete: bias (+ ReLU) -> LDS
+            constexpr int S = bias_slot(U);
+            constexpr bool last = L == 2;
+            lds_f32* dst = buf(L + 1) + n * LD + 16 * tile<U>() + 4 * g;
+            f32x4 y0, y1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y0[e] = last ? acc0[e] + B0[S][e] : fmaxf(acc0[e] + B0[S][e], 0.f);
+                y1[e] = last ? acc1[e] + B1[S][e] : fmaxf(acc1[e] + B1[S][e], 0.f);
+            }
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(dst) = y0;
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(dst + 16) = y1;
+        }
+        if constexpr (more) unit<U + 1>();
+    }
+};
+
+template <int K0, int D1, int D2, int D3>
+__global__ __launch_bounds__(64 * TS_WAVES) void tower_pipe_kernel(TowerSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float act[];         // [2][TS_ROWS][ld_act]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long row0 = (long long)blockIdx.x * TS_ROWS;
+    TowerPipe<K0, D1, D2, D3> P{a, (lds_f32*)act, a.ld_act, wave, lane & 15, lane >> 4};
+    P.template issue_bias<0>();
+    P.template issue<0>();
+    {   // input rows -> buf[0][row][0 .. K0), zero beyond dims[0]; its loads are the compiler's own, behind the ones above
+        constexpr int chunks = K0 >> 2;
+        for (int i = tid; i < TS_ROWS * chunks; i += 64 * TS_WAVES) {
+            const int r = i / chunks, k = (i - r * chunks) << 2;
+            const f32x4 v = a.in.load(a.in.row_state(row0 + r), k);
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(P.buf(0) + r * P.LD + k) = v;
+        }
+    }
+    P.template unit<0>();
+    __syncthreads();
+    normalize_rows_out(P.buf(3), P.LD, D3, row0, a, wave, lane);
 }
 
 // eligibility: every hidden / output width a multiple of 16 (whole output tiles, and the next layer's K needs no padding)
@@ -195,8 +321,26 @@ hipError_t tower_small_run(const amdrec_tower_params* p, const long long* cat, c
         if (e != hipSuccess) return e;
         attr_done.mark();
     }
+    const dim3 grid((unsigned)((rows + TS_ROWS - 1) / TS_ROWS)), block(64 * TS_WAVES);
+    // the reference's towers (user: 109 -> 512 -> 256 -> 256, ad: 320 -> 512 -> 256 -> 256) as one software pipeline
+    if (p->n_layers == 3 && p->dims[1] == 512 && p->dims[2] == 256 && p->dims[3] == 256 && (a.kp[0] == 128 || a.kp[0] == 384)) {
+        static PerDeviceOnce attr_pipe;
+        if (attr_pipe.pending()) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_pipe_kernel<128, 512, 256, 256>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TS_ROWS * (TS_MAX_WIDTH + 4) * 4);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_pipe_kernel<384, 512, 256, 256>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TS_ROWS * (TS_MAX_WIDTH + 4) * 4);
+            if (e != hipSuccess) return e;
+            attr_pipe.mark();
+        }
+        ProfScope prof("tower_pipe_16rows", flops * (double)rows, (double)rows * 4.0 * (p->dims[0] + p->dims[p->n_layers]), st);
+        if (a.kp[0] == 128) hipLaunchKernelGGL((tower_pipe_kernel<128, 512, 256, 256>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((tower_pipe_kernel<384, 512, 256, 256>), grid, block, lds, st, a);
+        return hipGetLastError();
+    }
     ProfScope prof("tower_fused_16rows", flops * (double)rows, (double)rows * 4.0 * (p->dims[0] + p->dims[p->n_layers]), st);
-    hipLaunchKernelGGL(tower_small_kernel, dim3((unsigned)((rows + TS_ROWS - 1) / TS_ROWS)), dim3(64 * TS_WAVES), lds, st, a);
+    hipLaunchKernelGGL(tower_small_kernel, grid, block, lds, st, a);
     return hipGetLastError();
 }
 
