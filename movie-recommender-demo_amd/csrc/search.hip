@@ -1126,17 +1126,27 @@ __global__ __launch_bounds__(512, 2) void finalize_mixed_kernel(unsigned long lo
             if (lane == 0 && i < m) keys[i] = (v == v) ? make_key(v, pos[u]) : 0ull;
         }
     }
-    int P2 = 2;
-    while (P2 < m) P2 <<= 1;
     __syncthreads();
-    for (int i = m + tid; i < P2; i += 512) keys[i] = 0ull;
-    __syncthreads();
-    bitonic_desc(keys, P2);
+    const unsigned long long* sorted = keys;
+    if (m <= 2048) {                                          // (cap = 8192 keys of LDS: source and destination both fit)
+        const int N = m <= 1024 ? 1024 : 2048;
+        for (int i = tid; i < N; i += 512) keys[N + i] = 0ull;   // NaN re-scores (key 0) are not placed by the run sort
+        __syncthreads();
+        if (m <= 1024) sort_desc_runs<2>(keys, keys + N, m);
+        else sort_desc_runs<4>(keys, keys + N, m);
+        sorted = keys + N;
+    } else {
+        int P2 = 2;
+        while (P2 < m) P2 <<= 1;
+        for (int i = m + tid; i < P2; i += 512) keys[i] = 0ull;
+        __syncthreads();
+        bitonic_desc(keys, P2);
+    }
     // certificate (block-uniform): rows outside the list have exact < tau + eps
-    const unsigned long long kth = keys[need - 1];
+    const unsigned long long kth = sorted[need - 1];
     const bool all_rows = (long long)c >= nrows;
     if (!all_rows && !(kth != 0ull && key_score(kth) >= tau[q] + eps)) { give_up(); return; }
-    write_result(keys, m, k, q, outD, outI, pos_offset);
+    write_result(sorted, m, k, q, outD, outI, pos_offset);
 }
 
 // re-score slice `blockIdx.x` of query `blockIdx.y`'s survivors in fp32: key(approx, pos) -> key(exact, pos), in place.
@@ -1409,14 +1419,14 @@ __global__ __launch_bounds__(512) void finalize_fused_kernel(const unsigned long
     __syncthreads();
     if (!last_sh) return;                                      // block-uniform
     // the query's last workgroup: all m exact keys are in the list (NaN re-scores as key 0: they sort last, as before)
-    if (m <= 1024) {
-        for (int i = tid; i < 1024; i += 512) keys[i] = i < m ? list[i] : 0ull;
+    if (m <= 2048) {
+        const int N = m <= 1024 ? 1024 : 2048;
+        // zero keys (NaN re-scores) are not placed by the run sort: the destination starts cleared
+        for (int i = tid; i < N; i += 512) { keys[i] = i < m ? list[i] : 0ull; keys[N + i] = 0ull; }
         __syncthreads();
-        // zero keys (NaN re-scores) are not placed by the run sort: clear the destination's tail first
-        for (int i = tid; i < 1024; i += 512) keys[1024 + i] = 0ull;
-        __syncthreads();
-        sort_desc_runs(keys, keys + 1024, m);
-        const unsigned long long* sorted = keys + 1024;
+        if (m <= 1024) sort_desc_runs<2>(keys, keys + N, m);
+        else sort_desc_runs<4>(keys, keys + N, m);
+        const unsigned long long* sorted = keys + N;
         const unsigned long long kth = sorted[need - 1];
         const bool all_rows = (long long)c >= nrows;
         if (!all_rows && !(kth != 0ull && key_score(kth) >= tau[q] + eps)) {

@@ -76,32 +76,43 @@ __device__ inline void bitonic_desc(unsigned long long* buf, int P) {
     }
 }
 
-// Descending sort of m <= 1024 keys in LDS by a 512-thread block, keys UNIQUE and non-zero (0 = padding): `src`[0 .. m) ->
-// `dst`[0 .. m) (two different arrays of >= 1024 keys; `src` is overwritten).  Each of the 8 waves sorts a run of 128 keys
-// in registers (two per lane, a 28-stage bitonic network on shuffles), the runs go back to `src`, and every key finds its
-// final position as its index in its own run + the number of larger keys in each other run (an 8-step binary search per
-// run: the runs are sorted and the keys unique).  ~4 us against ~17 for the all-LDS bitonic network of the same size (66
-// stages, most of them behind a block barrier) - the single-query search's finalize was the sort.
+// Descending sort of m <= 512 R keys in LDS by a 512-thread block (R = 2 or 4 keys per lane), keys UNIQUE and non-zero
+// (0 = padding): `src`[0 .. m) -> `dst`[0 .. m) (two different arrays of >= 512 R keys; `src` is overwritten; positions of
+// `dst` that receive no key keep their contents: clear them first if zeros can occur among the m).  Each of the 8 waves
+// sorts a run of 64 R keys in registers (a bitonic network on shuffles: 28 stages at R = 2, 36 at R = 4), the runs go back to
+// `src`, and every key finds its final position as its index in its own run + the number of larger keys in each other run
+// (a binary search per run: the runs are sorted and the keys unique).  ~4 us at 1024 keys against ~17 for the all-LDS
+// bitonic network (66 stages, most of them behind a block barrier) - the single-query search's finalize was the sort.
+template <int R>
 __device__ inline void sort_desc_runs(unsigned long long* src, unsigned long long* dst, int m) {
+    static_assert(R == 2 || R == 4, "two or four keys per lane");
+    constexpr int RUN = 64 * R, STEPS = R == 2 ? 8 : 9;      // binary search over 0 .. RUN
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    unsigned long long key[2];
+    unsigned long long key[R];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = 128 * w + 64 * r + lane;
+    for (int r = 0; r < R; ++r) {
+        const int i = RUN * w + 64 * r + lane;
         key[r] = i < m ? src[i] : 0ull;
     }
     __syncthreads();                                        // every key is in registers: `src` may be overwritten
 #pragma unroll
-    for (int k = 2; k <= 128; k <<= 1) {
+    for (int k = 2; k <= RUN; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j == 64) {                                   // k == 128: the partner is the lane's other register; descending
-                const unsigned long long a = key[0], b = key[1];
-                key[0] = a > b ? a : b;
-                key[1] = a > b ? b : a;
+            if (j >= 64) {                                   // the partner is another register of the same lane
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int pr = r ^ (j >> 6);
+                    if (pr < r) continue;                    // each pair once, from its lower element
+                    const bool desc = ((64 * r) & k) == 0;
+                    const unsigned long long a = key[r], b = key[pr];
+                    const bool swap = desc ? (a < b) : (a > b);
+                    key[r] = swap ? b : a;
+                    key[pr] = swap ? a : b;
+                }
             } else {
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
+                for (int r = 0; r < R; ++r) {
                     const int i = 64 * r + lane;
                     const unsigned long long other = __shfl_xor(key[r], j, 64);
                     const bool lower = (lane & j) == 0;          // i < partner
@@ -114,19 +125,19 @@ __device__ inline void sort_desc_runs(unsigned long long* src, unsigned long lon
         }
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) src[128 * w + 64 * r + lane] = key[r];
+    for (int r = 0; r < R; ++r) src[RUN * w + 64 * r + lane] = key[r];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < R; ++r) {
         if (key[r] == 0ull) continue;
         int rank = 64 * r + lane;
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             if (v == w) continue;
-            const unsigned long long* run = src + 128 * v;
-            int lo = 0, hi = 128;
+            const unsigned long long* run = src + RUN * v;
+            int lo = 0, hi = RUN;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {                 // keys of the run greater than mine: 0 .. 128 (zeros are smaller than any key)
+            for (int it = 0; it < STEPS; ++it) {             // keys of the run greater than mine: 0 .. RUN (zeros are smaller than any key)
                 const int mid = (lo + hi) >> 1;
                 if (lo < hi && run[mid] > key[r]) lo = mid + 1; else hi = mid;
             }
