@@ -27,6 +27,7 @@ namespace amdrec {
 constexpr int TS_ROWS = 16, TS_WAVES = 8;
 constexpr long long TS_MAX_ROWS = 4096;      // one 16-row workgroup per CU; beyond it the tiled GEMMs have enough work per launch
 constexpr int TS_MAX_WIDTH = 1024;
+constexpr long long TS_GEMV_MAX_ROWS = 2;   // rows that take the vector-ALU GEMV kernel (reference tower shapes)
 
 struct TowerSmallArgs {
     EmbConcatRows in;
@@ -281,6 +282,98 @@ __global__ __launch_bounds__(64 * TS_WAVES) void tower_pipe_kernel(TowerSmallArg
     normalize_rows_out(P.buf(3), P.LD, D3, row0, a, wave, lane);
 }
 
+// ---- one or two rows: a vector-ALU GEMV ---------------------------------------------------------------------------------
+// A single request's user row on the kernels above is a 16-row MFMA tile with 15 rows of padding: 8.4 MFLOP of fp32 MFMA on ONE
+// CU = 16 us of the 36.  Here a 512-thread workgroup per row computes 64 output features per pass, eight lanes per feature
+// (each reads 16 contiguous bytes of the feature's weight row per 32-k step, fp32 FMA chains, a three-step lane reduction);
+// the passes of all three layers are one compile-time list and pass p + 1's weight loads (they do not depend on the
+// activations) are issued before pass p's arithmetic, across the layer barriers (LDS-only fences: a __syncthreads() would
+// order - and wait for - the global loads too).  Bound: the row's 1 MB of weights through one CU's vector-memory pipeline.
+template <int K0, int D1, int D2, int D3>
+struct TowerGemv {
+    static constexpr int P0 = D1 / 64, P1 = D2 / 64, P2 = D3 / 64, NP = P0 + P1 + P2;
+    static constexpr int layer(int p) { return p < P0 ? 0 : (p < P0 + P1 ? 1 : 2); }
+    static constexpr int local(int p) { return p < P0 ? p : (p < P0 + P1 ? p - P0 : p - P0 - P1); }
+    static constexpr int kdim(int l) { return l == 0 ? K0 : (l == 1 ? D1 : D2); }
+    static constexpr int MAXS = (K0 > D1 ? (K0 > D2 ? K0 : D2) : (D1 > D2 ? D1 : D2)) / 32;
+    const TowerSmallArgs& a;
+    lds_f32* act;                       // [2][1024]
+    int n8, j;                          // feature within a pass (tid >> 3), lane of its group of eight
+    f32x4 W[2][MAXS];
+    float Bv[2];
+
+    template <int P>
+    __device__ __forceinline__ void load() {
+        constexpr int L = layer(P), S = kdim(L) / 32;
+        const int n = 64 * local(P) + n8;
+        const float* w = a.w[L] + (long long)n * a.ldw[L] + 4 * j;
+#pragma unroll
+        for (int i = 0; i < S; ++i) W[P & 1][i] = *reinterpret_cast<const f32x4*>(w + 32 * i);
+        Bv[P & 1] = a.b[L][n];
+    }
+    template <int P>
+    __device__ __forceinline__ void run() {
+        constexpr int L = layer(P), S = kdim(L) / 32;
+        if constexpr (P + 1 < NP) load<P + 1>();
+        if constexpr (local(P) == 0) {                          // the layer's input is complete (LDS traffic only)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const lds_f32* x = act + (L & 1) * 1024 + 4 * j;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const f32x4 xv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(x + 32 * i);
+            a0 = __builtin_fmaf(W[P & 1][i][0], xv[0], a0);
+            a1 = __builtin_fmaf(W[P & 1][i][1], xv[1], a1);
+            a2 = __builtin_fmaf(W[P & 1][i][2], xv[2], a2);
+            a3 = __builtin_fmaf(W[P & 1][i][3], xv[3], a3);
+        }
+        float v = (a0 + a1) + (a2 + a3);
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += Bv[P & 1];
+        if (j == 0) act[((L + 1) & 1) * 1024 + 64 * local(P) + n8] = L == 2 ? v : fmaxf(v, 0.f);
+        if constexpr (P + 1 < NP) run<P + 1>();
+    }
+};
+
+template <int K0, int D1, int D2, int D3>
+__global__ __launch_bounds__(512) void tower_gemv_kernel(TowerSmallArgs a) {
+    __shared__ __attribute__((aligned(16))) float act[2 * 1024];
+    const int tid = threadIdx.x;
+    const long long row = blockIdx.x;
+    TowerGemv<K0, D1, D2, D3> T{a, (lds_f32*)act, tid >> 3, tid & 7};
+    T.template load<0>();
+    if (tid < K0 / 4) {                                          // the input row (zero beyond dims[0])
+        const f32x4 v = a.in.load(a.in.row_state(row), 4 * tid);
+        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(T.act + 4 * tid) = v;
+    }
+    T.template run<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // F.normalize: the row's D3 outputs are in act[1024 ..) (three layers: buffer 1)
+    if (tid < 64) {
+        const lds_f32* y = T.act + 1024;
+        float ss = 0.f;
+        for (int c = 4 * tid; c < D3; c += 256) {
+            const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(y + c);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        float* o = a.out + row * a.ld_out;
+        for (int c = 4 * tid; c < D3; c += 256) {
+            f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(y + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] / nrm;
+            *reinterpret_cast<f32x4*>(o + c) = v;
+        }
+    }
+}
+
 // eligibility: every hidden / output width a multiple of 16 (whole output tiles, and the next layer's K needs no padding)
 bool tower_small_ok(const amdrec_tower_params* p, long long rows) {
     if (rows > TS_MAX_ROWS) return false;
@@ -333,6 +426,12 @@ hipError_t tower_small_run(const amdrec_tower_params* p, const long long* cat, c
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TS_ROWS * (TS_MAX_WIDTH + 4) * 4);
             if (e != hipSuccess) return e;
             attr_pipe.mark();
+        }
+        if (rows <= TS_GEMV_MAX_ROWS) {                  // one or two requests: no MFMA tile to fill
+            ProfScope prof("tower_gemv_1row", flops * (double)rows, (double)rows * 4.0 * (p->dims[0] + p->dims[p->n_layers]), st);
+            if (a.kp[0] == 128) hipLaunchKernelGGL((tower_gemv_kernel<128, 512, 256, 256>), dim3((unsigned)rows), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((tower_gemv_kernel<384, 512, 256, 256>), dim3((unsigned)rows), dim3(512), 0, st, a);
+            return hipGetLastError();
         }
         ProfScope prof("tower_pipe_16rows", flops * (double)rows, (double)rows * 4.0 * (p->dims[0] + p->dims[p->n_layers]), st);
         if (a.kp[0] == 128) hipLaunchKernelGGL((tower_pipe_kernel<128, 512, 256, 256>), grid, block, lds, st, a);
