@@ -944,72 +944,78 @@ __device__ __forceinline__ float eps_bound(float qn, float dqn, float M, float D
     return (dqn * (M + D) + qn * D) * 1.0001f + (float)d * 1.2e-7f * qn * (M + D);
 }
 
-// step 4 of the mixed-precision search: select a_k -> prune -> fp32 re-score -> exact sort -> certificate.
-// The candidate keys (<= 16 per thread) stay in registers for the selection: a 3-pass radix select of the k-th
-// largest approximate score (LDS histograms), then only the survivors of the pruning rule go to LDS, are re-scored
-// and sorted (typically ~1.25 k keys instead of the whole list).
-// SPLIT (small batches, <= SPLIT_MAX_NQ queries): the kernel stops after the prune and publishes the survivors (in place, at
-// the head of the query's candidate list) with their count and eps; finalize_rescore_kernel then spreads the re-scoring of
-// ONE query over several workgroups (a single block re-scoring ~1200 random 1 KB rows is latency-bound: 83 us at B = 1)
-// and finalize_sort_kernel sorts and certifies.  Large batches keep the fused form: one block per query already fills the chip.
+// step 4 of the mixed-precision search: select a_k -> prune -> fp32 re-score -> exact sort -> certificate, one workgroup per
+// query.  The candidate keys (<= CAPK / NT + overflow share per thread) stay in registers for the selection: a 3-pass radix
+// select of the k-th largest approximate score (LDS histograms), then only the survivors of the pruning rule go to LDS, are
+// re-scored and sorted (typically ~1.25 k keys instead of the whole list at k = 500).
+// Small batches (<= SPLIT_MAX_NQ queries) take finalize_fused_kernel below instead: several workgroups per query.
+// Shapes <NT threads, CAPK candidates>: <512, 8192> is the general one (two workgroups per CU: 64 KB of keys each).  The
+// sharded search asks for SHORT lists of MANY queries (8 ranks: 4096 queries x k = 128, ~400 candidates each), where a
+// workgroup's time is a chain of dependent steps (loads, three histogram passes, re-score rounds, sort), not work: 33 us per
+// query and only two chains in flight per CU - 0.26 ms of a rank's 0.68 ms search.  <128, 1024> and <256, 2048> keep 8 / 4
+// workgroups per CU in flight (16 waves either way); a query with more candidates than CAPK goes to the exact fix-up scan
+// (the host picks a shape with twice the expected count, 10 sigma of the threshold estimate).
 constexpr int SPLIT_MAX_NQ = 128;
 // Candidate input: block q of `cand` (cstride keys) = nseg segments of seg_cap slots, slot-major (slot s of segment g at
 // s * nseg + g) [+ an overflow block at CAND_CAP when the streaming pass produced it]; segcnt[q][nseg] = hits each segment
 // saw (may exceed seg_cap: the excess went to the overflow block, ocnt[q] entries).  The generic GEMM pass writes one
 // segment (nseg = 1, seg_cap = CAND_CAP, no overflow).
-template <bool SPLIT>
-__global__ __launch_bounds__(512, 2) void finalize_mixed_kernel(unsigned long long* cand, long long cstride, const int* segcnt,
-                                                             int nseg, int seg_cap, const int* ocnt, int cap,
-                                                             int k, long long nrows, const float* tau,
-                                                             const float* max_norm, const float* X, long long ldx,
-                                                             int d, const float* Q, long long ldq, int* fail,
-                                                             float* outD, long long* outI, long long pos_offset,
-                                                             int* m_out, float* eps_out, int* c_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [cap] then qv[d]
-    float* qv = reinterpret_cast<float*>(keys + cap);
+template <int NT, int CAPK>
+__global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void finalize_mixed_kernel(const unsigned long long* cand, long long cstride,
+                                                                       const int* segcnt, int nseg, int seg_cap, const int* ocnt,
+                                                                       int k, long long nrows, const float* tau,
+                                                                       const float* max_norm, const float* X, long long ldx,
+                                                                       int d, const float* Q, long long ldq, int* fail,
+                                                                       float* outD, long long* outI, long long pos_offset) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [CAPK] then qv[d]
+    float* qv = reinterpret_cast<float*>(keys + CAPK);
     __shared__ int hist[2048];
-    __shared__ int scratch[514];
+    __shared__ int scratch[NT + 2];
     __shared__ float red[16];
     __shared__ int m_sh;
-    __shared__ int seg_n[256], tot_sh, lost_sh;
-    constexpr int PER = CAND_CAP / 512;                       // segment slots per thread (cap == CAND_CAP)
-    constexpr int OVP = 4;                                    // overflow keys per thread: up to 2048 per query
+    __shared__ int seg_n[256], tot_sh, lost_sh, maxn_sh, fill_sh;
+    constexpr bool GENERAL = CAPK == CAND_CAP;                // threads read the slot-major candidate area directly
+    constexpr int NW = NT / 64;
+    constexpr int PER = CAPK / NT;                            // candidate keys per thread
+    constexpr int OVP = GENERAL ? 2048 / NT : 0;              // + overflow keys per thread (general shape: up to 2048 per query)
+    static_assert(!GENERAL || NT == 512, "the general shape is 512 threads");
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int need = (int)(nrows < k ? nrows : k);
     auto give_up = [&]() {
         if (tid == 0) {
             fail[q] = 1;
             atomicAdd(&fail[gridDim.x], 1);
-            if (SPLIT) m_out[q] = -1;                             // the follow-up kernels skip this query
         }
     };
     // segment counts: valid slots per segment, their total, and the hits that did not fit
-    if (tid == 0) { tot_sh = 0; lost_sh = 0; }
+    if (tid == 0) { tot_sh = 0; lost_sh = 0; maxn_sh = 0; fill_sh = 0; }
     __syncthreads();
-    int sv = 0, lost = 0;
-    if (tid < nseg) {
-        const int v = segcnt[(long long)q * nseg + tid];
-        sv = v < seg_cap ? v : seg_cap;
-        lost = v - sv;
-        seg_n[tid] = sv;
-    }
+    for (int g0 = 0; g0 < nseg; g0 += NT) {                   // (nseg <= 256)
+        int sv = 0, lost = 0;
+        if (g0 + tid < nseg) {
+            const int v = segcnt[(long long)q * nseg + g0 + tid];
+            sv = v < seg_cap ? v : seg_cap;
+            lost = v - sv;
+            seg_n[g0 + tid] = sv;
+            if (!GENERAL && sv) atomicMax(&maxn_sh, sv);
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        sv += __shfl_xor(sv, o, 64);
-        lost += __shfl_xor(lost, o, 64);
-    }
-    if (lane == 0 && w * 64 < nseg) {
-        atomicAdd(&tot_sh, sv);
-        if (lost) atomicAdd(&lost_sh, lost);
+        for (int o = 32; o > 0; o >>= 1) {
+            sv += __shfl_xor(sv, o, 64);
+            lost += __shfl_xor(lost, o, 64);
+        }
+        if (lane == 0) {
+            if (sv) atomicAdd(&tot_sh, sv);
+            if (lost) atomicAdd(&lost_sh, lost);
+        }
     }
     const int oc = ocnt[q];
     __syncthreads();
     const int c = tot_sh + oc;
     // every hit must be in a segment or in the overflow block, and the list must be usable (block-uniform tests)
-    if (lost_sh != oc || oc > 512 * OVP || c < need || c > cap) { give_up(); return; }
-    if (SPLIT && tid == 0) c_out[q] = c;
+    if (lost_sh != oc || oc > 2048 || c < need || c > CAPK) { give_up(); return; }
     float ss = 0.f, ds = 0.f;
-    for (int i = tid; i < d; i += 512) {
+    for (int i = tid; i < d; i += NT) {
         const float v = Q[(long long)q * ldq + i];
         qv[i] = v;
         ss += v * v;
@@ -1024,36 +1030,50 @@ __global__ __launch_bounds__(512, 2) void finalize_mixed_kernel(unsigned long lo
     }
     if (lane == 0) { red[w] = ss; red[8 + w] = ds; }
     if (tid == 0) m_sh = 0;
-    // the candidates stay where the pass put them: thread <- slots tid + 512 j of the segment area, validity from the
-    // segment's count (an empty slot is key 0, which no hit can be: its score would have to be NaN)
     const unsigned long long* blk = cand + (long long)q * cstride;
     const int nslots = nseg * seg_cap;
     const int seg_shift = (nseg & (nseg - 1)) == 0 ? 31 - __builtin_clz((unsigned)nseg) : -1;      // nseg a power of two
     unsigned long long mine[PER + OVP];
+    if constexpr (GENERAL) {
+        // the candidates stay where the pass put them: thread <- slots tid + NT j of the segment area, validity from the
+        // segment's count (an empty slot is key 0, which no hit can be: its score would have to be NaN)
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int s_ = tid + 512 * j;                          // slot-major: element (slot, segment) at slot * nseg + segment
-        bool ok = false;
-        if (s_ < nslots) {
-            const int slot = seg_shift >= 0 ? s_ >> seg_shift : s_ / nseg;
-            ok = slot < seg_n[s_ - slot * nseg];
+        for (int j = 0; j < PER; ++j) {
+            const int s_ = tid + NT * j;                       // slot-major: element (slot, segment) at slot * nseg + segment
+            bool ok = false;
+            if (s_ < nslots) {
+                const int slot = seg_shift >= 0 ? s_ >> seg_shift : s_ / nseg;
+                ok = slot < seg_n[s_ - slot * nseg];
+            }
+            mine[j] = ok ? blk[s_] : 0ull;
         }
-        mine[j] = ok ? blk[s_] : 0ull;
-    }
 #pragma unroll
-    for (int j = 0; j < OVP; ++j) {
-        const int i = tid + 512 * j;
-        mine[PER + j] = (i < oc) ? blk[CAND_CAP + i] : 0ull;
+        for (int j = 0; j < OVP; ++j) {
+            const int i = tid + NT * j;
+            mine[PER + j] = (i < oc) ? blk[CAND_CAP + i] : 0ull;
+        }
+        __syncthreads();
+    } else {
+        // short lists: the occupied prefix of the slot-major area (slots below the fullest segment's count) and the overflow
+        // block are compacted through LDS, then dealt to the threads' registers
+        const int lim = maxn_sh * nseg;
+        for (int s_ = tid; s_ < lim; s_ += NT) {
+            const int slot = seg_shift >= 0 ? s_ >> seg_shift : s_ / nseg;
+            if (slot < seg_n[s_ - slot * nseg]) keys[atomicAdd(&fill_sh, 1)] = blk[s_];
+        }
+        for (int i = tid; i < oc; i += NT) keys[atomicAdd(&fill_sh, 1)] = blk[CAND_CAP + i];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) mine[j] = (tid + NT * j < c) ? keys[tid + NT * j] : 0ull;
+        __syncthreads();                                      // keys[] is reused for the survivors
     }
-    __syncthreads();
     float qn = 0.f, dqn = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { qn += red[i]; dqn += red[8 + i]; }
+    for (int i = 0; i < NW; ++i) { qn += red[i]; dqn += red[8 + i]; }
     const float eps = eps_bound(sqrtf(qn), sqrtf(dqn) * 1.0001f, max_norm[0], max_norm[1], d);
     if (!(eps < INFINITY)) { give_up(); return; }            // NaN / inf norms: exact path (block-uniform)
     if (need == 0) {
         write_result(keys, 0, k, q, outD, outI, pos_offset);
-        if (SPLIT && tid == 0) m_out[q] = -1;
         return;
     }
     // a_k = need-th largest approximate score (orderable 32-bit image), radix select 11 + 11 + 10 bits
@@ -1063,7 +1083,7 @@ __global__ __launch_bounds__(512, 2) void finalize_mixed_kernel(unsigned long lo
     const int nbits[3] = {11, 11, 10};
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
-        for (int i = tid; i < 2048; i += 512) hist[i] = 0;
+        for (int i = tid; i < 2048; i += NT) hist[i] = 0;
         __syncthreads();
         const uint32_t bm = (1u << nbits[pass]) - 1u;
 #pragma unroll
@@ -1072,7 +1092,7 @@ __global__ __launch_bounds__(512, 2) void finalize_mixed_kernel(unsigned long lo
             if (mine[j] != 0ull && (u & pmask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & bm], 1);
         }
         __syncthreads();
-        const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);      // always found: c >= need >= rr
+        const int bin = find_bin_desc<2048, NT>(hist, rr, scratch);       // always found: c >= need >= rr
         prefix |= (uint32_t)bin << shifts[pass];
         pmask |= bm << shifts[pass];
     }
@@ -1083,23 +1103,18 @@ __global__ __launch_bounds__(512, 2) void finalize_mixed_kernel(unsigned long lo
         if (mine[j] != 0ull && key_score(mine[j]) >= cut) keys[atomicAdd(&m_sh, 1)] = mine[j];
     __syncthreads();
     const int m = m_sh;                                       // need <= m <= c
-    if constexpr (SPLIT) {                                    // publish: survivors overwrite the head of the candidate list
-        for (int i = tid; i < m; i += 512) cand[(long long)q * cstride + i] = keys[i]; // (every thread read its share above)
-        if (tid == 0) { m_out[q] = m; eps_out[q] = eps; }
-        return;
-    }
     // fp32 re-score, one wave per candidate, 8 candidates (random 1 KB rows: latency-bound) in flight per wave; two
     // workgroups per CU (<= 128 VGPRs): with 16 in flight the kernel needed 169 and ran one workgroup per CU, its select
     // and sort phases - barriers and LDS latency - covered by nothing
     const int d4 = d >> 2;
     constexpr int RU = 8;
-    for (int i0 = w; i0 < m; i0 += 8 * RU) {
+    for (int i0 = w; i0 < m; i0 += NW * RU) {
         float a[RU];
         uint32_t pos[RU];
         const f32x4* xr[RU];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
-            const int i = i0 + 8 * u;
+            const int i = i0 + NW * u;
             a[u] = 0.f;
             pos[u] = key_pos(keys[i < m ? i : i0]);
             xr[u] = reinterpret_cast<const f32x4*>(X + (long long)pos[u] * ldx);
@@ -1121,24 +1136,26 @@ __global__ __launch_bounds__(512, 2) void finalize_mixed_kernel(unsigned long lo
             float v = a[u];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            const int i = i0 + 8 * u;
+            const int i = i0 + NW * u;
             // a NaN re-score (inf - inf in fp32 that the bf16 pass did not produce) ranks last, as in the fix-up scan
             if (lane == 0 && i < m) keys[i] = (v == v) ? make_key(v, pos[u]) : 0ull;
         }
     }
     __syncthreads();
     const unsigned long long* sorted = keys;
-    if (m <= 2048) {                                          // (cap = 8192 keys of LDS: source and destination both fit)
+    if (NT == 512 && m <= 2048) {                             // (8192 keys of LDS: source and destination both fit)
         const int N = m <= 1024 ? 1024 : 2048;
-        for (int i = tid; i < N; i += 512) keys[N + i] = 0ull;   // NaN re-scores (key 0) are not placed by the run sort
+        for (int i = tid; i < N; i += NT) keys[N + i] = 0ull;    // NaN re-scores (key 0) are not placed by the run sort
         __syncthreads();
-        if (m <= 1024) sort_desc_runs<2>(keys, keys + N, m);
-        else sort_desc_runs<4>(keys, keys + N, m);
+        if constexpr (NT == 512) {
+            if (m <= 1024) sort_desc_runs<2>(keys, keys + N, m);
+            else sort_desc_runs<4>(keys, keys + N, m);
+        }
         sorted = keys + N;
     } else {
         int P2 = 2;
         while (P2 < m) P2 <<= 1;
-        for (int i = m + tid; i < P2; i += 512) keys[i] = 0ull;
+        for (int i = m + tid; i < P2; i += NT) keys[i] = 0ull;
         __syncthreads();
         bitonic_desc(keys, P2);
     }
@@ -1147,80 +1164,6 @@ __global__ __launch_bounds__(512, 2) void finalize_mixed_kernel(unsigned long lo
     const bool all_rows = (long long)c >= nrows;
     if (!all_rows && !(kth != 0ull && key_score(kth) >= tau[q] + eps)) { give_up(); return; }
     write_result(sorted, m, k, q, outD, outI, pos_offset);
-}
-
-// re-score slice `blockIdx.x` of query `blockIdx.y`'s survivors in fp32: key(approx, pos) -> key(exact, pos), in place.
-// Same per-row arithmetic as the fused kernel (one wave per row, one explicit fma chain): a row's score does not depend on
-// which kernel, slice or slot computed it.
-__global__ __launch_bounds__(256) void finalize_rescore_kernel(unsigned long long* cand, long long cap, const int* m_in,
-                                                               const float* X, long long ldx, int d, const float* Q,
-                                                               long long ldq) {
-    __shared__ __attribute__((aligned(16))) float qv[2048];
-    const int q = blockIdx.y, m = m_in[q];
-    if (m <= 0) return;
-    const int per = (m + gridDim.x - 1) / gridDim.x;
-    const int lo = blockIdx.x * per, hi = lo + per < m ? lo + per : m;
-    if (lo >= hi) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int i = tid; i < d; i += 256) qv[i] = Q[(long long)q * ldq + i];
-    __syncthreads();
-    unsigned long long* keys = cand + (long long)q * cap;        // cap = keys between the queries' blocks
-    const int d4 = d >> 2;
-    constexpr int RU = 16, NW = 4;
-    for (int i0 = lo + w; i0 < hi; i0 += NW * RU) {
-        float a[RU];
-        uint32_t pos[RU];
-        const f32x4* xr[RU];
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const int i = i0 + NW * u;
-            a[u] = 0.f;
-            pos[u] = key_pos(keys[i < hi ? i : i0]);
-            xr[u] = reinterpret_cast<const f32x4*>(X + (long long)pos[u] * ldx);
-        }
-        for (int cc = lane; cc < d4; cc += 64) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(&qv[4 * cc]);
-            f32x4 x[RU];
-#pragma unroll
-            for (int u = 0; u < RU; ++u) x[u] = xr[u][cc];
-#pragma unroll
-            for (int u = 0; u < RU; ++u)
-                a[u] = __builtin_fmaf(x[u][3], y[3], __builtin_fmaf(x[u][2], y[2], __builtin_fmaf(x[u][1], y[1],
-                                      __builtin_fmaf(x[u][0], y[0], a[u]))));
-        }
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            float v = a[u];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            const int i = i0 + NW * u;
-            if (lane == 0 && i < hi) keys[i] = (v == v) ? make_key(v, pos[u]) : 0ull;
-        }
-    }
-}
-
-// sort the re-scored survivors, certify (rows outside the list have exact < tau + eps), write
-__global__ __launch_bounds__(512) void finalize_sort_kernel(const unsigned long long* cand, const int* cnt, long long cap, int k,
-                                                            long long nrows, const float* tau, const int* m_in,
-                                                            const float* eps_in, int* fail, float* outD, long long* outI,
-                                                            long long pos_offset) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const int m = m_in[q];
-    if (m <= 0) return;                                       // given up (or nothing to do) in the select kernel
-    const int need = (int)(nrows < k ? nrows : k);
-    int P2 = 2;
-    while (P2 < m) P2 <<= 1;
-    for (int i = tid; i < P2; i += 512) keys[i] = i < m ? cand[(long long)q * cap + i] : 0ull;
-    __syncthreads();
-    bitonic_desc(keys, P2);
-    const unsigned long long kth = keys[need - 1];
-    const bool all_rows = (long long)cnt[q] >= nrows;
-    if (!all_rows && !(kth != 0ull && key_score(kth) >= tau[q] + eps_in[q])) {
-        if (tid == 0) { fail[q] = 1; atomicAdd(&fail[gridDim.x], 1); }
-        return;
-    }
-    write_result(keys, m, k, q, outD, outI, pos_offset);
 }
 
 // Small batches (<= SPLIT_MAX_NQ queries), round 3: select -> prune -> re-score -> sort -> certificate in ONE launch of
@@ -1461,7 +1404,8 @@ struct SearchPlan {
     long long gstride;       // rows between sample blocks
     int rank;                // r
     int nslices;             // fix-up slices
-    size_t off_tau, off_cnt, off_ocnt, off_ticket, off_fcount, off_fticket, off_fail, off_segcnt, off_cand, off_sample, off_fix, off_q16, off_m, off_eps, off_exact, bytes;
+    long long target;        // expected candidates per query (0: every row is a candidate)
+    size_t off_tau, off_cnt, off_ocnt, off_ticket, off_fcount, off_fticket, off_fail, off_segcnt, off_cand, off_sample, off_fix, off_q16, off_exact, bytes;
 };
 
 // dim16 > 0: the mixed-precision search, which also keeps a bf16 copy of the queries in the workspace
@@ -1485,6 +1429,7 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
         if (opt < t5) t5 = opt;
     }
     long long target = (2ll * k > t5) ? 2ll * k : t5;
+    pl.target = nrows <= CAND_CAP ? 0 : target;
     if (nrows <= CAND_CAP) {
         pl.n_sample = 0;                  // every row becomes a candidate
         pl.gstride = SAMPLE_G;
@@ -1514,8 +1459,6 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
     pl.off_sample = o; o = align_up(o + (size_t)nq * (size_t)pl.n_sample * 4, 256);
     pl.off_fix = o;    o = align_up(o + (size_t)nq * pl.nslices * k * 8, 256);
     pl.off_q16 = o;    o = align_up(o + (size_t)nq * (size_t)dim16 * 2, 256);
-    pl.off_m = o;      o = align_up(o + (size_t)(dim16 ? nq : 0) * 8, 256);      // split finalize: survivors | candidates per query, eps per query
-    pl.off_eps = o;    o = align_up(o + (size_t)(dim16 ? nq : 0) * 4, 256);
     pl.off_exact = o;  o = align_up(o + (size_t)(dim16 && nq <= SPLIT_MAX_NQ ? nq : 0) * CAND_CAP * 8, 256);   // fused finalize: re-scored keys
     pl.bytes = o;
     return 0;
@@ -1777,12 +1720,8 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     const size_t fin_lds = (size_t)CAND_CAP * 8 + (size_t)dim * 4;
     static PerDeviceOnce attr_done;
     if (attr_done.pending()) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_mixed_kernel<false>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_mixed_kernel<512, CAND_CAP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_mixed_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_sort_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_fused_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CAND_CAP * 8 + 2048 * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fixup_kernel),
@@ -1804,10 +1743,17 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
                                reinterpret_cast<unsigned long long*>(ws + pl.off_exact),
                                reinterpret_cast<int*>(ws + pl.off_fcount), reinterpret_cast<int*>(ws + pl.off_fticket));
         } else {
-            hipLaunchKernelGGL(finalize_mixed_kernel<false>, dim3((unsigned)nq), dim3(512), fin_lds, st, cand, CSTRIDE, segcnt, nseg,
-                               seg_cap, (const int*)ocnt, CAND_CAP, k, (long long)nrows, tau, max_norm, corpus,
-                               (long long)ld_corpus, dim, queries, (long long)ld_queries, fail, out_scores,
-                               (long long*)out_pos, (long long)pos_offset, (int*)nullptr, (float*)nullptr, (int*)nullptr);
+            // one workgroup per query; short lists of many queries (the sharded search) on the small shapes: twice the
+            // expected candidate count must fit (10 sigma of the threshold estimate; beyond it the query takes the fix-up scan)
+#define AMDREC_FINALIZE(NT_, CAPK_)                                                                                          \
+    hipLaunchKernelGGL((finalize_mixed_kernel<NT_, CAPK_>), dim3((unsigned)nq), dim3(NT_), (size_t)(CAPK_) * 8 + (size_t)dim * 4, \
+                       st, (const unsigned long long*)cand, CSTRIDE, segcnt, nseg, seg_cap, (const int*)ocnt, k,             \
+                       (long long)nrows, tau, max_norm, corpus, (long long)ld_corpus, dim, queries, (long long)ld_queries,    \
+                       fail, out_scores, (long long*)out_pos, (long long)pos_offset)
+            if (pl.target > 0 && 2 * pl.target <= 1024 && dim <= 2048) AMDREC_FINALIZE(128, 1024);
+            else if (pl.target > 0 && 2 * pl.target <= 2048 && dim <= 2048) AMDREC_FINALIZE(256, 2048);
+            else AMDREC_FINALIZE(512, CAND_CAP);
+#undef AMDREC_FINALIZE
         }
     }
     ProfScope prof_fix("search_fixup", 0.0, 0.0, st);
