@@ -948,14 +948,14 @@ __device__ __forceinline__ float eps_bound(float qn, float dqn, float M, float D
 // query.  The candidate keys (<= CAPK / NT + overflow share per thread) stay in registers for the selection: a 3-pass radix
 // select of the k-th largest approximate score (LDS histograms), then only the survivors of the pruning rule go to LDS, are
 // re-scored and sorted (typically ~1.25 k keys instead of the whole list at k = 500).
-// Small batches (<= SPLIT_MAX_NQ queries) take finalize_fused_kernel below instead: several workgroups per query.
+// Small batches (<= FUSED_MAX_NQ queries) take finalize_fused_kernel below instead: several workgroups per query.
 // Shapes <NT threads, CAPK candidates>: <512, 8192> is the general one (two workgroups per CU: 64 KB of keys each).  The
 // sharded search asks for SHORT lists of MANY queries (8 ranks: 4096 queries x k = 128, ~400 candidates each), where a
 // workgroup's time is a chain of dependent steps (loads, three histogram passes, re-score rounds, sort), not work: 33 us per
 // query and only two chains in flight per CU - 0.26 ms of a rank's 0.68 ms search.  <128, 1024> and <256, 2048> keep 8 / 4
 // workgroups per CU in flight (16 waves either way); a query with more candidates than CAPK goes to the exact fix-up scan
 // (the host picks a shape with twice the expected count, 10 sigma of the threshold estimate).
-constexpr int SPLIT_MAX_NQ = 128;
+constexpr int FUSED_MAX_NQ = 128;
 // Candidate input: block q of `cand` (cstride keys) = nseg segments of seg_cap slots, slot-major (slot s of segment g at
 // s * nseg + g) [+ an overflow block at CAND_CAP when the streaming pass produced it]; segcnt[q][nseg] = hits each segment
 // saw (may exceed seg_cap: the excess went to the overflow block, ocnt[q] entries).  The generic GEMM pass writes one
@@ -1166,9 +1166,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void finalize_mixed_kernel(c
     write_result(sorted, m, k, q, outD, outI, pos_offset);
 }
 
-// Small batches (<= SPLIT_MAX_NQ queries), round 3: select -> prune -> re-score -> sort -> certificate in ONE launch of
+// Small batches (<= FUSED_MAX_NQ queries), round 3: select -> prune -> re-score -> sort -> certificate in ONE launch of
 // gridDim.x workgroups per query (the three kernels above cost 38 us at one query: 12.5 + 8 + 17, each of the small ones
-// mostly launch-to-drain latency).  Every workgroup of a query repeats the select + prune on the query's candidates (the same
+// mostly launch-to-drain latency; they are gone).  Every workgroup of a query repeats the select + prune on the query's candidates (the same
 // deterministic result in each: redundant, but in parallel), re-scores the survivors whose corpus position falls to it
 // (pos % gridDim.x: a share that does not depend on the order in which a block's threads compacted the survivors), appends
 // the exact keys to the query's list in the workspace, and takes a ticket; the workgroup that draws the LAST ticket (agent-scope
@@ -1459,7 +1459,7 @@ static int make_plan(long long nq, long long nrows, int k, SearchPlan& pl, int d
     pl.off_sample = o; o = align_up(o + (size_t)nq * (size_t)pl.n_sample * 4, 256);
     pl.off_fix = o;    o = align_up(o + (size_t)nq * pl.nslices * k * 8, 256);
     pl.off_q16 = o;    o = align_up(o + (size_t)nq * (size_t)dim16 * 2, 256);
-    pl.off_exact = o;  o = align_up(o + (size_t)(dim16 && nq <= SPLIT_MAX_NQ ? nq : 0) * CAND_CAP * 8, 256);   // fused finalize: re-scored keys
+    pl.off_exact = o;  o = align_up(o + (size_t)(dim16 && nq <= FUSED_MAX_NQ ? nq : 0) * CAND_CAP * 8, 256);   // fused finalize: re-scored keys
     pl.bytes = o;
     return 0;
 }
@@ -1733,7 +1733,7 @@ extern "C" int amdrec_flat_search_mixed(const float* corpus, int64_t nrows, int6
     const float* tau = reinterpret_cast<const float*>(ws + pl.off_tau);
     {
         ProfScope prof("search_finalize_mixed", 0.0, 0.0, st);
-        if (nq <= SPLIT_MAX_NQ) {
+        if (nq <= FUSED_MAX_NQ) {
             int slices = (int)(512 / nq);                           // ~512 workgroups in all: the chip once
             slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
             hipLaunchKernelGGL(finalize_fused_kernel, dim3((unsigned)slices, (unsigned)nq), dim3(512), fin_lds, st,
