@@ -1172,8 +1172,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 4) void finalize_mixed_kernel(c
 // deterministic result in each: redundant, but in parallel), re-scores the survivors whose corpus position falls to it
 // (pos % gridDim.x: a share that does not depend on the order in which a block's threads compacted the survivors), appends
 // the exact keys to the query's list in the workspace, and takes a ticket; the workgroup that draws the LAST ticket (agent-scope
-// release / acquire around it, as in fixup_kernel) sorts the list - sort_desc_runs for <= 1024 survivors -, certifies and
-// writes the result.  Same per-row re-score arithmetic, same prune, same certificate as the kernels above.
+// release / acquire around it, as in fixup_kernel) sorts the list - sort_desc_runs for <= 2048 survivors -, certifies and
+// writes the result.  Same per-row re-score arithmetic, same prune rule, same certificate as finalize_mixed_kernel.
 __global__ __launch_bounds__(512) void finalize_fused_kernel(const unsigned long long* cand, long long cstride, const int* segcnt,
                                                              int nseg, int seg_cap, const int* ocnt, int cap, int k,
                                                              long long nrows, const float* tau, const float* max_norm,
