@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMDREC_ABI_VERSION 7
+#define AMDREC_ABI_VERSION 8
 #define AMDREC_MAX_K 2048
 
 int amdrec_abi_version(void);
@@ -168,6 +168,10 @@ typedef struct {
     const int32_t* cards;        /* device [n_feat]: cardinality of column f */
     const float* w[AMDREC_MAX_LAYERS];
     const float* b[AMDREC_MAX_LAYERS];
+    /* != 0: amdrec_l2_normalize applied to the output rows in the same call - the rows go to an inner-product search
+     * that normalises its queries (faiss.normalize_L2 on the tower's already normalised output, faiss_retrieval.py:147
+     * after two_tower_model.py:121): the same two roundings as the two calls, one launch fewer. */
+    int32_t renormalize;
 } amdrec_tower_params;
 
 int amdrec_tower_workspace(const amdrec_tower_params* p /*host*/, int64_t rows, size_t* bytes /*host*/);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AMDREC_LIB_PATH: developer override for A/B runs of two builds of the library in otherwise identical processes
 LIB_PATH = os.environ.get("AMDREC_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libamdrec.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_K = 2048
 
 

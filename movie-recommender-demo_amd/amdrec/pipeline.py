@@ -162,8 +162,9 @@ class AdRecommenderInference:
 
     # -- the device hot path ------------------------------------------------------------------
     def _stage1(self, uc, un, stage1_k, check_indices):
-        emb = self.two_tower_model.user_tower.encode(uc, un, check_indices=check_indices)      # :223-227
-        return self.faiss_index.search_device(emb, stage1_k, normalize=True,                   # :230-232
+        # the tower's launch also applies the search's query normalisation (faiss_retrieval.py:147): one launch fewer
+        emb = self.two_tower_model.user_tower.encode(uc, un, check_indices=check_indices, renormalize=True)   # :223-227
+        return self.faiss_index.search_device(emb, stage1_k, normalize=False,                  # :230-232
                                               return_positions=True)
 
     def _stage2(self, uc, un, cand_pos, top_k, check_indices, ids_are_positions=False):

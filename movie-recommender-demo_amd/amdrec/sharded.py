@@ -71,8 +71,8 @@ class HipEngine:
         self.shard_offset = int(shard_offset)
 
     def local_search(self, uc, un, k):
-        emb = self.rec.two_tower_model.user_tower.encode(uc, un, check_indices=False)
-        pos, scores = self.rec.faiss_index.search_device(emb, k, normalize=True, return_positions=True,
+        emb = self.rec.two_tower_model.user_tower.encode(uc, un, check_indices=False, renormalize=True)
+        pos, scores = self.rec.faiss_index.search_device(emb, k, normalize=False, return_positions=True,
                                                          pos_offset=self.shard_offset)
         return scores, pos
 

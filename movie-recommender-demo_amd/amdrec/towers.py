@@ -73,8 +73,14 @@ class _Tower(nn.Module):
             x = torch.cat([x, num], dim=1)                                                                 # :113
         return torch.nn.functional.normalize(self.mlp(x), p=2, dim=1)                                      # :116-119
 
-    def encode(self, cat: torch.Tensor, num: torch.Tensor = None, check_indices: bool = True) -> torch.Tensor:
+    def encode(self, cat: torch.Tensor, num: torch.Tensor = None, check_indices: bool = True,
+               renormalize: bool = False) -> torch.Tensor:
+        """``renormalize``: also apply ``faiss.normalize_L2`` to the (already normalised) rows in the same launch, for a
+        caller that feeds them to ``FAISSIndex.search_device(..., normalize=False)`` - the serving path's second
+        normalisation (faiss_retrieval.py:147) without its own kernel launch; bit-identical to the two calls."""
         if self.training:
+            if renormalize:
+                raise ValueError("renormalize is an inference-path option")
             return self.autograd_forward(cat, num)
         cat = _lib.require_gpu(cat, "categorical_features")
         dev = cat.device
@@ -89,6 +95,7 @@ class _Tower(nn.Module):
         else:
             num = None
         params = self._pack(dev)
+        params.renormalize = 1 if renormalize else 0
         lib = _lib.load()
         out = torch.empty((rows, self.output_dim), dtype=torch.float32, device=dev)
         if rows == 0:

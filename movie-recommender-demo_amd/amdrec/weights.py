@@ -20,7 +20,7 @@ class TowerParams(C.Structure):
     _fields_ = [("n_feat", C.c_int32), ("emb_dim", C.c_int32), ("n_num", C.c_int32), ("n_layers", C.c_int32),
                 ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("ldw", C.c_int32 * MAX_LAYERS),
                 ("tables", _FP), ("table_off", _FP), ("cards", _FP),
-                ("w", _FP * MAX_LAYERS), ("b", _FP * MAX_LAYERS)]
+                ("w", _FP * MAX_LAYERS), ("b", _FP * MAX_LAYERS), ("renormalize", C.c_int32)]
 
 
 class EncoderLayer(C.Structure):

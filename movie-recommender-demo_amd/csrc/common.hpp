@@ -59,6 +59,13 @@ __host__ __device__ inline float f32_from_orderable(uint32_t k) {
     return f;
 #endif
 }
+// v0^2 + v1^2 + v2^2 + v3^2 as ONE explicit fma chain: the row-norm kernels (amdrec_l2_normalize, the towers' fused second
+// normalisation) must round identically, and a sum of products left to the compiler is contracted differently from one
+// context to the next
+__device__ __forceinline__ float sumsq4(const f32x4& v) {
+    return __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], v[0] * v[0])));
+}
+
 __host__ __device__ inline unsigned long long make_key(float score, uint32_t pos) {
     return ((unsigned long long)f32_orderable(score) << 32) | (unsigned long long)(~pos);
 }

@@ -600,6 +600,8 @@ extern "C" int amdrec_tower_forward(const amdrec_tower_params* p, const int64_t*
             HIP_TRY(e);
         }
     }
+    if (p->renormalize)                                   // the general path: a second launch (amdrec_l2_normalize in place)
+        return amdrec_l2_normalize(out, ld_out, out, ld_out, rows, p->dims[p->n_layers], stream);
     return AMDREC_OK;
 }
 

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* in, long
     float ss = 0.f;
     for (int c = lane; c < d4; c += 64) {
         f32x4 v = src[c];
-        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        ss += sumsq4(v);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);

@@ -41,6 +41,7 @@ struct TowerSmallArgs {
     long long ld_out;
     long long rows;
     int ld_act;                                // floats between the rows of an activation buffer
+    int renorm;                                // amdrec_tower_params.renormalize
 };
 
 // LDS pointers keep their address space: through a generic pointer (e.g. an array of two buffer pointers indexed at run time)
@@ -84,20 +85,66 @@ __device__ __forceinline__ void normalize_rows_out(const lds_f32* fin, int LD, i
         float ss = 0.f;
         for (int c = 4 * lane; c < nout; c += 256) {
             const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
-            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            ss += sumsq4(v);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        float inv = 1.0f;
+        if (a.renorm) {                                      // amdrec_l2_normalize of the normalised row: l2_normalize_kernel's
+            float s2 = 0.f;                                  // lane map and expressions (csrc/rows.hip), so the same bits
+            for (int c = 4 * lane; c < nout; c += 256) {
+                f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] / nrm;
+                s2 += sumsq4(v);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
+        }
         if (row0 + r < a.rows) {
             float* o = a.out + (row0 + r) * a.ld_out;
             for (int c = 4 * lane; c < nout; c += 256) {
                 f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] / nrm;
+                if (a.renorm) v = f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
                 *reinterpret_cast<f32x4*>(o + c) = v;
             }
         }
+    }
+}
+
+// one row, one wave (the GEMV kernel): normalize_rows_out's arithmetic
+__device__ __forceinline__ void normalize_rows_out_single(const lds_f32* xr, int nout, const TowerSmallArgs& a, int lane) {
+    float ss = 0.f;
+    for (int c = 4 * lane; c < nout; c += 256) {
+        const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
+        ss += sumsq4(v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    float inv = 1.0f;
+    if (a.renorm) {
+        float s2 = 0.f;
+        for (int c = 4 * lane; c < nout; c += 256) {
+            f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] / nrm;
+            s2 += sumsq4(v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
+    }
+    for (int c = 4 * lane; c < nout; c += 256) {
+        f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(xr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / nrm;
+        if (a.renorm) v = f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+        *reinterpret_cast<f32x4*>(a.out + c) = v;
     }
 }
 
@@ -353,24 +400,12 @@ __global__ __launch_bounds__(512) void tower_gemv_kernel(TowerSmallArgs a) {
     T.template run<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // F.normalize: the row's D3 outputs are in act[1024 ..) (three layers: buffer 1)
+    // F.normalize: the row's D3 outputs are in act[1024 ..) (three layers: buffer 1); wave 0, the lane map of the kernels above
     if (tid < 64) {
-        const lds_f32* y = T.act + 1024;
-        float ss = 0.f;
-        for (int c = 4 * tid; c < D3; c += 256) {
-            const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(y + c);
-            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-        float* o = a.out + row * a.ld_out;
-        for (int c = 4 * tid; c < D3; c += 256) {
-            f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(y + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] / nrm;
-            *reinterpret_cast<f32x4*>(o + c) = v;
-        }
+        TowerSmallArgs one = a;
+        one.rows = 1;
+        one.out = a.out + row * a.ld_out;
+        normalize_rows_out_single(T.act + 1024, D3, one, tid);
     }
 }
 
@@ -404,7 +439,7 @@ hipError_t tower_small_run(const amdrec_tower_params* p, const long long* cat, c
             flops += 2.0 * p->dims[l] * p->dims[l + 1];
         }
     }
-    a.out = out; a.ld_out = ld_out; a.rows = rows;
+    a.out = out; a.ld_out = ld_out; a.rows = rows; a.renorm = p->renormalize;
     a.ld_act = wmax + 4;                                  // + 16 bytes: rows of a buffer start on different banks
     const size_t lds = 2ull * TS_ROWS * a.ld_act * sizeof(float);
     static PerDeviceOnce attr_done;

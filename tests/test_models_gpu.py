@@ -68,9 +68,30 @@ def test_towers_large_batch_vs_oracle_crosses_row_passes():
     assert np.abs(np.linalg.norm(ae, axis=1) - 1).max() <= 1e-5
 
 
+@pytest.mark.parametrize("name", ["demo", "ragged"])
+@pytest.mark.parametrize("rows", [1, 2, 7, 512, 5000])
+def test_tower_renormalize_equals_a_separate_l2_normalize_launch(name, rows):
+    """``encode(..., renormalize=True)`` - the serving path's tower launch that also applies the search's query
+    normalisation (faiss_retrieval.py:147) - against ``encode()`` followed by ``amdrec_l2_normalize``: the same bits, on the
+    one-row GEMV kernel (<= 2 rows), the 16-row kernels (<= 4096) and the tiled-GEMM path (beyond)."""
+    from amdrec import _lib
+    m, sd, (user, ad, nnum), _ = _two_tower(name)
+    uc, un = synth.user_batch(user, nnum, rows, seed=rows)
+    uc, un = _cu(uc), _cu(un)
+    plain = m.user_tower.encode(uc, un)
+    fused = m.user_tower.encode(uc, un, renormalize=True)
+    ref = torch.empty_like(plain)
+    _lib.check(_lib.load().amdrec_l2_normalize(_lib.ptr(plain), plain.stride(0), _lib.ptr(ref), ref.stride(0), rows,
+                                               plain.shape[1], _lib.stream_ptr(plain.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(fused, ref)
+    assert torch.equal(m.user_tower.encode(uc, un), plain)           # the flag does not stick to the packed parameters
+    assert (fused.norm(dim=1) - 1).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
 @pytest.mark.parametrize("engine", ["f16x3", "fp32", "bf16x6"])
 @pytest.mark.parametrize("cross", list(cases.CROSS))
-@pytest.mark.parametrize("name", list(cases.CASES))
 def test_ranker_matches_reference_golden(name, cross, engine, accuracy):
     """The reference's own outputs (tests/golden, generated from the imported transformer_ranker.py) against EVERY
     engine: the default row-owner kernel (f16x3 takes every batch since x3_min_rows = 1), the strict fp32-MFMA engine
