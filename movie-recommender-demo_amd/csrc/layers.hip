@@ -711,7 +711,7 @@ extern "C" int amdrec_ranker_project_ads(const amdrec_ranker_params* p, const in
 // stages the user's 205 features in LDS and computes 32 output features, eight lanes per feature: the eight read 128
 // contiguous bytes of the weight row per step (7 steps, all in flight), fp32 FMA chains, then a three-step lane reduction.
 // (One thread per output feature reads its row alone: 64 cache lines per load instruction, 12 us on one CU.)
-constexpr int USER_PROJ_SMALL_MAX = 16, USER_PROJ_SMALL_K = 256;     // users per call; features (8 steps of 32)
+constexpr int USER_PROJ_SMALL_MAX = 64, USER_PROJ_SMALL_K = 256;     // users per call; features (8 steps of 32)
 __global__ __launch_bounds__(256) void user_proj_small_kernel(EmbConcatRows g, const float* W, int ldw, int K, const float* bias,
                                                               float* U, int dm) {
     __shared__ __attribute__((aligned(16))) float feat[USER_PROJ_SMALL_K];

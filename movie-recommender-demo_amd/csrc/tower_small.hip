@@ -27,7 +27,7 @@ namespace amdrec {
 constexpr int TS_ROWS = 16, TS_WAVES = 8;
 constexpr long long TS_MAX_ROWS = 4096;      // one 16-row workgroup per CU; beyond it the tiled GEMMs have enough work per launch
 constexpr int TS_MAX_WIDTH = 1024;
-constexpr long long TS_GEMV_MAX_ROWS = 2;   // rows that take the vector-ALU GEMV kernel (reference tower shapes)
+constexpr long long TS_GEMV_MAX_ROWS = 256; // rows that take the vector-ALU GEMV kernel (reference tower shapes): one workgroup per row and CU
 
 struct TowerSmallArgs {
     EmbConcatRows in;

@@ -143,9 +143,9 @@ def test_ranker_unfused_attention_matches_too():
         assert ok, (t, err)
 
 
-@pytest.mark.parametrize("name,U,k", [("ragged", 7, 500), ("demo", 1, 500), ("demo", 16, 100), ("demo", 17, 100)])
+@pytest.mark.parametrize("name,U,k", [("ragged", 7, 500), ("demo", 1, 500), ("demo", 64, 100), ("demo", 65, 100)])
 def test_ranker_score_candidates_broadcast_and_gather(name, U, k):
-    """The hoisted form: user half of the projection once per user (<= 16 users: csrc/layers.hip user_proj_small_kernel,
+    """The hoisted form: user half of the projection once per user (<= 64 users: csrc/layers.hip user_proj_small_kernel,
     beyond: the tile GEMM), candidate half gathered from the resident ad table."""
     m, sd, (user, ad, nnum), _ = _ranker(name, "scaled")
     N = 5000
