@@ -27,7 +27,7 @@ namespace amdrec {
 constexpr int TS_ROWS = 16, TS_WAVES = 8;
 constexpr long long TS_MAX_ROWS = 4096;      // one 16-row workgroup per CU; beyond it the tiled GEMMs have enough work per launch
 constexpr int TS_MAX_WIDTH = 1024;
-constexpr long long TS_GEMV_MAX_ROWS = 256; // rows that take the vector-ALU GEMV kernel (reference tower shapes): one workgroup per row and CU
+constexpr long long TS_GEMV_MAX_ROWS = 1024; // rows that take the vector-ALU GEMV kernel (reference tower shapes): 1 / 2 / 4 rows per workgroup, one workgroup per CU
 
 struct TowerSmallArgs {
     EmbConcatRows in;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void tower_pipe_kernel(TowerSmallArg
 // the passes of all three layers are one compile-time list and pass p + 1's weight loads (they do not depend on the
 // activations) are issued before pass p's arithmetic, across the layer barriers (LDS-only fences: a __syncthreads() would
 // order - and wait for - the global loads too).  Bound: the row's 1 MB of weights through one CU's vector-memory pipeline.
-template <int K0, int D1, int D2, int D3>
+template <int K0, int D1, int D2, int D3, int R>
 struct TowerGemv {
     static constexpr int P0 = D1 / 64, P1 = D2 / 64, P2 = D3 / 64, NP = P0 + P1 + P2;
     static constexpr int layer(int p) { return p < P0 ? 0 : (p < P0 + P1 ? 1 : 2); }
@@ -344,7 +344,7 @@ struct TowerGemv {
     static constexpr int kdim(int l) { return l == 0 ? K0 : (l == 1 ? D1 : D2); }
     static constexpr int MAXS = (K0 > D1 ? (K0 > D2 ? K0 : D2) : (D1 > D2 ? D1 : D2)) / 32;
     const TowerSmallArgs& a;
-    lds_f32* act;                       // [2][1024]
+    lds_f32* act;                       // [R][2][1024]: the workgroup's R rows, two ping-pong buffers each
     int n8, j;                          // feature within a pass (tid >> 3), lane of its group of eight
     f32x4 W[2][MAXS];
     float Bv[2];
@@ -366,46 +366,53 @@ struct TowerGemv {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        const lds_f32* x = act + (L & 1) * 1024 + 4 * j;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-        for (int i = 0; i < S; ++i) {
-            const f32x4 xv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(x + 32 * i);
-            a0 = __builtin_fmaf(W[P & 1][i][0], xv[0], a0);
-            a1 = __builtin_fmaf(W[P & 1][i][1], xv[1], a1);
-            a2 = __builtin_fmaf(W[P & 1][i][2], xv[2], a2);
-            a3 = __builtin_fmaf(W[P & 1][i][3], xv[3], a3);
+        for (int r = 0; r < R; ++r) {                           // the pass's weights, once loaded, serve every row of the workgroup
+            const lds_f32* x = act + r * 2048 + (L & 1) * 1024 + 4 * j;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const f32x4 xv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(x + 32 * i);
+                a0 = __builtin_fmaf(W[P & 1][i][0], xv[0], a0);
+                a1 = __builtin_fmaf(W[P & 1][i][1], xv[1], a1);
+                a2 = __builtin_fmaf(W[P & 1][i][2], xv[2], a2);
+                a3 = __builtin_fmaf(W[P & 1][i][3], xv[3], a3);
+            }
+            float v = (a0 + a1) + (a2 + a3);
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += Bv[P & 1];
+            if (j == 0) act[r * 2048 + ((L + 1) & 1) * 1024 + 64 * local(P) + n8] = L == 2 ? v : fmaxf(v, 0.f);
         }
-        float v = (a0 + a1) + (a2 + a3);
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += Bv[P & 1];
-        if (j == 0) act[((L + 1) & 1) * 1024 + 64 * local(P) + n8] = L == 2 ? v : fmaxf(v, 0.f);
         if constexpr (P + 1 < NP) run<P + 1>();
     }
 };
 
-template <int K0, int D1, int D2, int D3>
+// R rows per workgroup: one row per workgroup up to a chip-full of rows (256), then two and four - the weights are read once
+// per workgroup whatever R is, and the arithmetic is nothing
+template <int K0, int D1, int D2, int D3, int R>
 __global__ __launch_bounds__(512) void tower_gemv_kernel(TowerSmallArgs a) {
-    __shared__ __attribute__((aligned(16))) float act[2 * 1024];
+    __shared__ __attribute__((aligned(16))) float act[R * 2 * 1024];
     const int tid = threadIdx.x;
-    const long long row = blockIdx.x;
-    TowerGemv<K0, D1, D2, D3> T{a, (lds_f32*)act, tid >> 3, tid & 7};
+    const long long row0 = (long long)blockIdx.x * R;
+    TowerGemv<K0, D1, D2, D3, R> T{a, (lds_f32*)act, tid >> 3, tid & 7};
     T.template load<0>();
-    if (tid < K0 / 4) {                                          // the input row (zero beyond dims[0])
-        const f32x4 v = a.in.load(a.in.row_state(row), 4 * tid);
-        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(T.act + 4 * tid) = v;
+    for (int i = tid; i < R * (K0 / 4); i += 512) {              // the input rows (zero beyond dims[0]; past the end: clamped)
+        const int r = i / (K0 / 4), c = i - r * (K0 / 4);
+        const f32x4 v = a.in.load(a.in.row_state(row0 + r), 4 * c);
+        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(T.act + r * 2048 + 4 * c) = v;
     }
     T.template run<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // F.normalize: the row's D3 outputs are in act[1024 ..) (three layers: buffer 1); wave 0, the lane map of the kernels above
-    if (tid < 64) {
+    // F.normalize: row r's D3 outputs are in its buffer 1 (three layers); wave r, the lane map of the kernels above
+    const int w = tid >> 6;
+    if (w < R && row0 + w < a.rows) {
         TowerSmallArgs one = a;
         one.rows = 1;
-        one.out = a.out + row * a.ld_out;
-        normalize_rows_out_single(T.act + 1024, D3, one, tid);
+        one.out = a.out + (row0 + w) * a.ld_out;
+        normalize_rows_out_single(T.act + w * 2048 + 1024, D3, one, tid & 63);
     }
 }
 
@@ -462,10 +469,14 @@ hipError_t tower_small_run(const amdrec_tower_params* p, const long long* cat, c
             if (e != hipSuccess) return e;
             attr_pipe.mark();
         }
-        if (rows <= TS_GEMV_MAX_ROWS) {                  // one or two requests: no MFMA tile to fill
+        if (rows <= TS_GEMV_MAX_ROWS) {                  // up to four rows per workgroup and one workgroup per CU: no MFMA tile to fill
             ProfScope prof("tower_gemv_1row", flops * (double)rows, (double)rows * 4.0 * (p->dims[0] + p->dims[p->n_layers]), st);
-            if (a.kp[0] == 128) hipLaunchKernelGGL((tower_gemv_kernel<128, 512, 256, 256>), dim3((unsigned)rows), dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((tower_gemv_kernel<384, 512, 256, 256>), dim3((unsigned)rows), dim3(512), 0, st, a);
+            const int R = rows <= 256 ? 1 : (rows <= 512 ? 2 : 4);
+            const dim3 g((unsigned)((rows + R - 1) / R));
+#define AMDREC_GEMV(K0_, R_) hipLaunchKernelGGL((tower_gemv_kernel<K0_, 512, 256, 256, R_>), g, dim3(512), 0, st, a)
+            if (a.kp[0] == 128) { if (R == 1) AMDREC_GEMV(128, 1); else if (R == 2) AMDREC_GEMV(128, 2); else AMDREC_GEMV(128, 4); }
+            else                { if (R == 1) AMDREC_GEMV(384, 1); else if (R == 2) AMDREC_GEMV(384, 2); else AMDREC_GEMV(384, 4); }
+#undef AMDREC_GEMV
             return hipGetLastError();
         }
         ProfScope prof("tower_pipe_16rows", flops * (double)rows, (double)rows * 4.0 * (p->dims[0] + p->dims[p->n_layers]), st);

@@ -68,12 +68,26 @@ def test_towers_large_batch_vs_oracle_crosses_row_passes():
     assert np.abs(np.linalg.norm(ae, axis=1) - 1).max() <= 1e-5
 
 
+@pytest.mark.parametrize("rows", [300, 511, 701, 2000])
+def test_demo_towers_mid_batches_vs_oracle(rows):
+    """The reference tower shapes between the golden batches (<= 64 rows) and the large-batch test: the GEMV kernel with 2 and 4
+    rows per workgroup (257 .. 1024 rows, ragged tails) and the pipelined 16-row MFMA kernel (.. 4096), user tower
+    (K0 = 128) and ad tower (K0 = 384)."""
+    m, sd, (user, ad, nnum), _ = _two_tower("demo")
+    uc, un = synth.user_batch(user, nnum, rows, seed=rows)
+    ac = synth.ad_features(ad, rows, seed=rows + 1)
+    ue = m.get_user_embeddings(_cu(uc), _cu(un)).cpu().numpy()
+    ae = m.get_ad_embeddings(_cu(ac)).cpu().numpy()
+    assert np.abs(ue - oracle.towers.user_tower(sd, uc, un)).max() <= cases.EMB_ATOL
+    assert np.abs(ae - oracle.towers.ad_tower(sd, ac)).max() <= cases.EMB_ATOL
+
+
 @pytest.mark.parametrize("name", ["demo", "ragged"])
-@pytest.mark.parametrize("rows", [1, 2, 7, 512, 5000])
+@pytest.mark.parametrize("rows", [1, 2, 7, 301, 512, 701, 5000])
 def test_tower_renormalize_equals_a_separate_l2_normalize_launch(name, rows):
     """``encode(..., renormalize=True)`` - the serving path's tower launch that also applies the search's query
     normalisation (faiss_retrieval.py:147) - against ``encode()`` followed by ``amdrec_l2_normalize``: the same bits, on the
-    one-row GEMV kernel (<= 2 rows), the 16-row kernels (<= 4096) and the tiled-GEMM path (beyond)."""
+    GEMV kernel (<= 1024 rows: 1, 2 or 4 rows per workgroup), the 16-row kernels (<= 4096) and the tiled-GEMM path (beyond)."""
     from amdrec import _lib
     m, sd, (user, ad, nnum), _ = _two_tower(name)
     uc, un = synth.user_batch(user, nnum, rows, seed=rows)
