@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMDREC_ABI_VERSION 8
+#define AMDREC_ABI_VERSION 9
 #define AMDREC_MAX_K 2048
 
 int amdrec_abi_version(void);
@@ -104,6 +104,13 @@ int amdrec_ivf_coarse_keys(const float* centroids, int nlist, int64_t ld_centroi
 int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count /*[nq]*/,
                       int64_t nq, int k, float* out_scores /*[nq][k]*/, int64_t* out_pos /*[nq][k]*/,
                       void* stream);
+/* The same selection for FEW queries with LARGE pools (one request against nlist 100 / nprobe 10 at 1M ads: 100 000 keys):
+ * `slices` workgroups per query select the k best of a slice of the pool each into workspace[nq][slices][k] (64-bit keys:
+ * nq * slices * k * 8 bytes), the last one to finish (a ticket per query: tickets[nq], int32, zero on entry, zero again
+ * on return) selects the k best of those.  Same result as amdrec_ivf_select. */
+int amdrec_ivf_select_split(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count /*[nq]*/, int64_t nq, int k,
+                            int slices, float* out_scores, int64_t* out_pos, void* workspace, size_t workspace_bytes,
+                            int32_t* tickets, void* stream);
 /* Step 2 as kernels (no host sync, capturable): from probes[nq][nprobe] and the list lengths, the pool layout
  * (pool_base[nq][nprobe], pool_count[nq]) and the (query, probe) pairs grouped by list for amdrec_ivf_scan_grouped
  * (pair_query / pair_probe [nq*nprobe], group_off / qtile_prefix [nlist+1]; order inside a group is unspecified - it

@@ -36,7 +36,9 @@ QTILE = 64                     # queries per grouped-scan tile (ShapeIvf::BP) ..
 QTILE_SPARSE = 32              # ... or 32 (ShapeIvf32) when fewer than SPARSE_PAIRS_PER_LIST queries probe a list on average
 SPARSE_PAIRS_PER_LIST = 24
 MAX_QUERY_TILES = 65535        # grid limit of one amdrec_ivf_scan_grouped launch (pairs / tile + nlist query tiles)
-TWO_PHASE_MIN_PROBES = 16      # from here on the scan is split: nearest probes unfiltered, the rest filtered by their k-th score
+SELECT_SLICE_KEYS = 4096        # amdrec_ivf_select_split: at least this many pool keys per slice,
+SELECT_MAX_SLICES = 64          # at most this many slices per query
+TWO_PHASE_MIN_PROBES = 16      # from here on the scan is split: nearest probes unfiltered, the rest filtered by their k-th score (at 10 probes it loses: 0.78 vs 0.41 ms at 64 queries, nlist 100)
 
 
 def _normalize(x):
@@ -78,6 +80,8 @@ class IVFState:
         self._lists = None                                          # (xs, spos, list_off, list_len, max_len)
         self._top_rows = None                                       # host: rows of the p longest lists (pool_rows_bound)
         self._nlist_count = None                                    # device: nlist per query (the coarse select's pool sizes)
+        self._sel_scratch = None                                    # device: amdrec_ivf_select_split's partial lists and tickets
+        self._sel_tickets = None
 
     # -- build ----------------------------------------------------------------------------
     @classmethod
@@ -132,6 +136,23 @@ class IVFState:
         if self._top_rows is None or len(self._top_rows) == 0:
             return 1
         return max(1, int(self._top_rows[min(int(nprobe), len(self._top_rows)) - 1]))
+
+    def _select(self, lib, pool, pool_ld: int, n_pool, m: int, k: int, out_scores, out_pos, stream_ptr):
+        """The k best keys of each query's pool.  Few queries with large pools (one request against nlist 100 / nprobe 10:
+        100 000 keys) are selected by several workgroups per query (``amdrec_ivf_select_split``), everything else by one."""
+        slices = min(SELECT_MAX_SLICES, pool_ld // SELECT_SLICE_KEYS, 1024 // max(1, m))
+        if slices < 4:
+            _lib.check(lib.amdrec_ivf_select(_lib.ptr(pool), pool_ld, _lib.ptr(n_pool), m, k, _lib.ptr(out_scores),
+                                             _lib.ptr(out_pos), stream_ptr))
+            return
+        need = m * slices * k * 8
+        if self._sel_scratch is None or self._sel_scratch.numel() < need:
+            self._sel_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self._sel_tickets is None or self._sel_tickets.numel() < m:
+            self._sel_tickets = torch.zeros(max(m, 1024), dtype=torch.int32, device=self.device)   # the kernel leaves them zero
+        _lib.check(lib.amdrec_ivf_select_split(_lib.ptr(pool), pool_ld, _lib.ptr(n_pool), m, k, slices, _lib.ptr(out_scores),
+                                               _lib.ptr(out_pos), _lib.ptr(self._sel_scratch), self._sel_scratch.numel(),
+                                               _lib.ptr(self._sel_tickets), stream_ptr))
 
     # -- search ---------------------------------------------------------------------------
     def search(self, xb: torch.Tensor, n: int, q: torch.Tensor, k: int, nprobe: int, out_scores: torch.Tensor,
@@ -211,8 +232,7 @@ class IVFState:
             m = min(chunk, nq - s)
             if two_phase:
                 group_and_scan(s, m, 0, n_first, n_out=n_pool[s:])
-                _lib.check(lib.amdrec_ivf_select(_lib.ptr(ws), pool_ld, _lib.ptr(n_pool[s:]), m, k,
-                                                 _lib.ptr(out_scores[s:]), _lib.ptr(out_pos[s:]), st()))
+                self._select(lib, ws, pool_ld, n_pool[s:], m, k, out_scores[s:], out_pos[s:], st())
                 group_and_scan(s, m, n_first, nprobe - n_first, tau=out_scores[s:, k - 1], fill=n_pool[s:], n_out=scratch_n)
             elif grouped:
                 group_and_scan(s, m, 0, nprobe, n_out=n_pool[s:])
@@ -223,8 +243,7 @@ class IVFState:
                 _lib.check(lib.amdrec_ivf_scan(_lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off),
                                                _lib.ptr(q[s:]), m, q.stride(0), _lib.ptr(probes[s:]),
                                                _lib.ptr(base[s:]), nprobe, _lib.ptr(ws), pool_ld, pos_offset, st()))
-            _lib.check(lib.amdrec_ivf_select(_lib.ptr(ws), pool_ld, _lib.ptr(n_pool[s:]), m, k,
-                                             _lib.ptr(out_scores[s:]), _lib.ptr(out_pos[s:]), st()))
+            self._select(lib, ws, pool_ld, n_pool[s:], m, k, out_scores[s:], out_pos[s:], st())
 
     # -- persistence ----------------------------------------------------------------------
     def export_arrays(self):

@@ -22,15 +22,25 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const float* xs, long lon
     const int q = blockIdx.y, p = blockIdx.x;
     const long long l = probes[(long long)q * nprobe + p];
     if (l < 0) return;
-    const long long r0 = list_off[l], r1 = list_off[l + 1];
+    const long long r0 = list_off[l];
+    long long r1 = list_off[l + 1];
     if (r1 <= r0) return;
+    // gridDim.z workgroups share the list's rows (whole 32-row rounds each): one request against the reference's default
+    // index (nlist 100, nprobe 10: ten lists of 10 000 rows at 1M ads) was ten workgroups streaming 10 MB each - 1 ms
+    long long rb = r0;
+    if (gridDim.z > 1) {
+        const long long per = ((r1 - r0 + gridDim.z - 1) / gridDim.z + 31) / 32 * 32;
+        rb = r0 + (long long)blockIdx.z * per;
+        if (rb >= r1) return;
+        if (rb + per < r1) r1 = rb + per;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < d; i += 256) qv[i] = Q[(long long)q * ldq + i];
     __syncthreads();
     unsigned long long* dst = keys + (long long)q * pool_ld + base[(long long)q * nprobe + p];
     const int d4 = d >> 2;
     constexpr int NW = 4, U = 8;
-    for (long long row0 = r0; row0 < r1; row0 += NW * U) {
+    for (long long row0 = rb; row0 < r1; row0 += NW * U) {
         float part[U];
         const f32x4* xr[U];
 #pragma unroll
@@ -219,17 +229,11 @@ __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
 // ties by position.  Four reads of the pool instead of the seven of a select over the whole 64-bit key; only when the
 // boundary score has so many ties that the gather would not fit (k + ties > 2048) does the kernel fall back to that
 // 6-pass select of the exact k-th key.
-__global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long long* keys, long long pool_ld,
-                                                         const long long* n_pool, int k, float* outD,
-                                                         long long* outI) {
-    __shared__ int hist[2048];
-    __shared__ int scratch[514];
-    __shared__ __attribute__((aligned(16))) unsigned long long buf[2048];
-    __shared__ int count;
-    const long long q = blockIdx.x;
+// the k best (by 64-bit key, descending) of row[0 .. n): sorted in buf[0 .. have), have = min(n, k) valid entries first
+// (keys of value 0 = empty slots rank last and are reported invalid by write_result).  All 512 threads call.
+__device__ __forceinline__ int select_sorted_keys(const unsigned long long* row, long long n, int k, int* hist, int* scratch,
+                                                  unsigned long long* buf, int* count) {
     const int tid = threadIdx.x;
-    const long long n = n_pool[q];
-    const unsigned long long* row = keys + q * pool_ld;
     unsigned long long kstar = 0ull;          // gather everything by default (n <= k)
     if (n > k) {
         uint32_t prefix = 0u, pmask = 0u;
@@ -252,18 +256,18 @@ __global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long lon
         kstar = (unsigned long long)prefix << 32;      // every key whose score is the k-th largest score or better
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (tid == 0) count = 0;
+        if (tid == 0) *count = 0;
         for (int i = tid; i < 2048; i += 512) buf[i] = 0ull;
         __syncthreads();
         for (long long i = tid; i < n; i += 512) {
             const unsigned long long key = row[i];
             if (key >= kstar) {
-                const int pos = atomicAdd(&count, 1);
+                const int pos = atomicAdd(count, 1);
                 if (pos < 2048) buf[pos] = key;
             }
         }
         __syncthreads();
-        if (count <= 2048 || attempt == 1) break;        // block-uniform
+        if (*count <= 2048 || attempt == 1) break;        // block-uniform
         // too many ties at the boundary score: the exact k-th KEY by a 6-pass select over all 64 bits, then exactly k pass
         unsigned long long prefix = 0ull, pmask = 0ull;
         int rr = k;
@@ -286,12 +290,62 @@ __global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long lon
         kstar = prefix;
         __syncthreads();
     }
-    const int have_all = count < 2048 ? count : 2048;
+    const int have_all = *count < 2048 ? *count : 2048;
     int P = 2;
     while (P < have_all) P <<= 1;             // >= k whenever n >= k (k <= 2048)
     bitonic_desc(buf, P);
-    const int have = have_all < k ? have_all : k;
+    return have_all < k ? have_all : k;
+}
+
+__global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long long* keys, long long pool_ld,
+                                                         const long long* n_pool, int k, float* outD,
+                                                         long long* outI) {
+    __shared__ int hist[2048];
+    __shared__ int scratch[514];
+    __shared__ __attribute__((aligned(16))) unsigned long long buf[2048];
+    __shared__ int count;
+    const long long q = blockIdx.x;
+    const int have = select_sorted_keys(keys + q * pool_ld, n_pool[q], k, hist, scratch, buf, &count);
     write_result(buf, have, k, q, outD, outI, 0);
+}
+
+// Few queries with LARGE pools (one request against nlist 100 / nprobe 10 at 1M ads: 100 000 keys, one workgroup walking
+// them four times: 0.14 ms): gridDim.x workgroups per query each select the k best of a slice of the pool into
+// part[q][slice][k]; the workgroup that draws the query's last ticket (agent-scope release / acquire, as in the flat
+// search's fix-up) selects the k best of those and writes the result.  The k best of the pool are among the k best of
+// the slices, and the order is the key order either way: the same result as ivf_select_kernel.  The ticket returns to 0.
+__global__ __launch_bounds__(512) void ivf_select_split_kernel(const unsigned long long* keys, long long pool_ld,
+                                                               const long long* n_pool, int k, unsigned long long* part,
+                                                               int* tickets, float* outD, long long* outI) {
+    __shared__ int hist[2048];
+    __shared__ int scratch[514];
+    __shared__ __attribute__((aligned(16))) unsigned long long buf[2048];
+    __shared__ int count, last_sh;
+    const long long q = blockIdx.y;
+    const int s = blockIdx.x, S = gridDim.x, tid = threadIdx.x;
+    const long long n = n_pool[q];
+    const long long per = (n + S - 1) / S;
+    const long long lo = s * per < n ? s * per : n, hi = lo + per < n ? lo + per : n;
+    const int have = select_sorted_keys(keys + q * pool_ld + lo, hi - lo, k, hist, scratch, buf, &count);
+    unsigned long long* mine = part + (q * S + s) * k;
+    for (int i = tid; i < k; i += 512) mine[i] = i < have ? buf[i] : 0ull;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(&tickets[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_sh = t == S - 1;
+        if (t == S - 1) {
+            __hip_atomic_store(&tickets[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next call
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!last_sh) return;                                      // block-uniform
+    const int have2 = select_sorted_keys(part + q * S * k, (long long)S * k, k, hist, scratch, buf, &count);
+    write_result(buf, have2, k, q, outD, outI, 0);
 }
 
 // ---- index BUILD: max-inner-product assignment and Lloyd iterations (faiss_retrieval.py:83-95, :118: IndexIVFFlat with an
@@ -547,7 +601,10 @@ extern "C" int amdrec_ivf_scan(const float* lists, int64_t ld, int dim, const in
     REQUIRE(nq <= 65535, "at most 65535 queries per call");
     REQUIRE(lists && row_pos && list_off && queries && probes && pool_base && pool_keys, "null pointer");
     REQUIRE(ld % 4 == 0 && ld >= dim && ld_queries >= dim, "bad leading dimension");
-    hipLaunchKernelGGL(ivf_scan_kernel, dim3(nprobe, (unsigned)nq), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    long long splits = 2048 / ((long long)nprobe * nq);            // ~2048 workgroups in all
+    splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+    ProfScope prof("ivf_scan_pairs", 0.0, 0.0, reinterpret_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(ivf_scan_kernel, dim3(nprobe, (unsigned)nq, (unsigned)splits), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        lists, (long long)ld, dim, (const long long*)row_pos, (const long long*)list_off, queries,
                        (long long)ld_queries, (const long long*)probes, (const long long*)pool_base, nprobe,
                        (unsigned long long*)pool_keys, (long long)pool_ld, (long long)pos_offset);
@@ -647,6 +704,26 @@ extern "C" int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, con
     hipLaunchKernelGGL(ivf_select_kernel, dim3((unsigned)nq), dim3(512), 0, reinterpret_cast<hipStream_t>(stream),
                        (const unsigned long long*)pool_keys, (long long)pool_ld, (const long long*)pool_count, k,
                        out_scores, (long long*)out_pos);
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_ivf_select_split(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count, int64_t nq,
+                                       int k, int slices, float* out_scores, int64_t* out_pos, void* workspace,
+                                       size_t workspace_bytes, int32_t* tickets, void* stream) {
+    REQUIRE(k >= 1 && k <= AMDREC_MAX_K, "k=%d outside [1,%d]", k, AMDREC_MAX_K);
+    REQUIRE(slices >= 1 && slices <= 1024 && nq <= 65535, "slices / nq out of range");
+    if (nq <= 0) return AMDREC_OK;
+    REQUIRE(pool_keys && pool_count && out_scores && out_pos && tickets, "null pointer");
+    const size_t need = (size_t)nq * slices * k * 8;
+    if (!workspace || workspace_bytes < need)
+        return set_error(AMDREC_EWORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
+    ProfScope prof("ivf_select", 0.0, 0.0, reinterpret_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(ivf_select_split_kernel, dim3((unsigned)slices, (unsigned)nq), dim3(512), 0,
+                       reinterpret_cast<hipStream_t>(stream), (const unsigned long long*)pool_keys, (long long)pool_ld,
+                       (const long long*)pool_count, k, reinterpret_cast<unsigned long long*>(workspace), tickets, out_scores,
+                       (long long*)out_pos);
     HIP_TRY(hipGetLastError());
     return AMDREC_OK;
 }

@@ -275,3 +275,40 @@ def test_coarse_key_table_gives_the_exact_search_probes(nlist, nprobe, nq):
     assert torch.equal(pr, pr2)
     ref = (q.double() @ cent.double().T).cpu().numpy()
     assert np.abs(np.sort(ref, axis=1)[:, ::-1][:, :nprobe] - cs2.cpu().numpy()).max() <= cases.SCORE_ATOL
+
+
+@pytest.mark.parametrize("nq,n,k,slices", [(1, 100_000, 500, 24), (3, 37_001, 500, 9), (2, 5_000, 500, 16), (5, 300, 500, 4),
+                                           (2, 70_000, 10, 64)])
+def test_split_select_equals_the_single_workgroup_select(nq, n, k, slices):
+    """amdrec_ivf_select_split (several workgroups per query, partial lists + a ticket) == amdrec_ivf_select, bit for bit:
+    pools with duplicated scores (ties broken by position), ragged pool sizes, fewer keys than k, repeated calls on the same
+    tickets (the kernel leaves them zero)."""
+    from amdrec import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + k)
+    sc = torch.randn(nq, n, generator=g)
+    sc[:, ::7] = sc[:, 1::7][:, :sc[:, ::7].shape[1]]          # exact score ties at different positions
+    pos = torch.stack([torch.randperm(n, generator=g) for _ in range(nq)])
+    u = sc.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    u = torch.where(u >= 0x80000000, (~u) & 0xFFFFFFFF, u | 0x80000000)              # order-preserving image of the score
+    keys = ((u << 32) | ((~pos) & 0xFFFFFFFF)).cuda()                                # make_key(score, position)
+    cnt = torch.tensor([n - 13 * i for i in range(nq)], dtype=torch.int64).clamp(min=1).cuda()
+    ref_s, ref_p = torch.empty((nq, k), device="cuda"), torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    _lib.check(lib.amdrec_ivf_select(_lib.ptr(keys), n, _lib.ptr(cnt), nq, k, _lib.ptr(ref_s), _lib.ptr(ref_p),
+                                     _lib.stream_ptr(keys.device)))
+    ws = torch.empty(nq * slices * k * 8, dtype=torch.uint8, device="cuda")
+    tickets = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        out_s, out_p = torch.full_like(ref_s, float("nan")), torch.full_like(ref_p, -7)
+        _lib.check(lib.amdrec_ivf_select_split(_lib.ptr(keys), n, _lib.ptr(cnt), nq, k, slices, _lib.ptr(out_s), _lib.ptr(out_p),
+                                               _lib.ptr(ws), ws.numel(), _lib.ptr(tickets), _lib.stream_ptr(keys.device)))
+        torch.cuda.synchronize()
+        assert torch.equal(out_p, ref_p) and torch.equal(out_s, ref_s)
+        assert int(tickets.abs().sum()) == 0
+    # against a plain sort of the first query's pool
+    c0 = int(cnt[0])
+    flipped = keys[0, :c0].cpu() ^ torch.iinfo(torch.int64).min      # unsigned 64-bit order as signed order
+    order = torch.argsort(flipped, descending=True, stable=True)[:k]
+    exp = pos[0][order]
+    have = min(k, c0)
+    assert torch.equal(ref_p[0, :have].cpu(), exp[:have])
