@@ -252,8 +252,16 @@ __device__ __forceinline__ int select_sorted_keys(const unsigned long long* row,
             const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);   // always found: n > k >= rr
             prefix |= (uint32_t)bin << shifts[pass];
             pmask |= bm << shifts[pass];
+            // keys at or above this bin's lower edge: the k - rr above the bin (rr = the k-th key's rank inside it) + the bin's
+            // own.  If they fit the sort buffer
+            // the remaining passes are not needed - the gather below takes exactly these and the sort finds the k best.
+            // Typical pools stop after the FIRST pass: two walks over the pool instead of four (the select of a large
+            // pool is bound by those walks: 512 queries x 100 000 keys, 0.46 ms).
+            const int at_or_above = (k - rr) + hist[bin];
+            __syncthreads();                                     // hist is cleared by the next pass
+            if (at_or_above <= 2048) break;                      // block-uniform
         }
-        kstar = (unsigned long long)prefix << 32;      // every key whose score is the k-th largest score or better
+        kstar = (unsigned long long)prefix << 32;      // every key at or above the k-th largest score's (partial) prefix
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (tid == 0) *count = 0;
