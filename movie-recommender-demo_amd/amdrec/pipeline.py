@@ -181,7 +181,9 @@ class AdRecommenderInference:
             cand_ids = cand_pos
         elif idx._identity:
             unfilled = idx._n and (stage1_k > idx._n or idx.index_type == "IVF")     # else every slot is filled
-            cand_ids = torch.where(cand_pos < 0, cand_pos + idx._n, cand_pos) if unfilled else cand_pos
+            # an unfilled slot (-1) reads id_map[-1] like the reference's list indexing (faiss_retrieval.py:159-160): one
+            # launch (Python-style remainder: -1 -> n - 1, valid positions unchanged) instead of compare + add + where
+            cand_ids = torch.remainder(cand_pos, idx._n) if unfilled else cand_pos
         else:
             cand_ids = torch.empty_like(cand_pos)
             _lib.check(lib.amdrec_remap_ids(_lib.ptr(cand_pos), _lib.ptr(idx._ids), idx._n, _lib.ptr(cand_ids),
