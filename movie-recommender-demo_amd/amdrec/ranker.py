@@ -114,6 +114,12 @@ class TransformerRanker(nn.Module):
     def invalidate(self):
         self._packed = None
         self._ad_cache = None
+        _lib.drop_tensor_list(self)
+
+    def _apply(self, fn, *a, **k):                 # .to() / .cuda() / .float(): tensors may be replaced
+        r = super()._apply(fn, *a, **k)
+        self.invalidate()
+        return r
 
     def cache_ad_projection(self, ad_table: Optional[torch.Tensor]):
         """Candidate-side cache for ``score_candidates``: the ad half of the feature projection,
@@ -159,7 +165,7 @@ class TransformerRanker(nn.Module):
             raise ValueError(f"gemm_engine must be one of {self.ENGINES}")
         key = (str(device), self.fuse_attention, self.gemm_engine, int(self.x3_min_rows), int(self.x3_variant),
                int(self.x3_cs_max_rows),
-               tuple(p._version for p in self.parameters()))
+               _lib.tensor_versions(self))
         if self._packed is None or self._packed[0] != key:
             sd = self.state_dict()
             x3 = self.gemm_engine == "f16x3" and weights.x3_eligible(sd, self.fuse_attention)

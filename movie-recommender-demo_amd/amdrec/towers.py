@@ -54,10 +54,15 @@ class _Tower(nn.Module):
 
     def invalidate(self):
         self._packed = None
+        _lib.drop_tensor_list(self)
+
+    def _apply(self, fn, *a, **k):                 # .to() / .cuda() / .float(): tensors may be replaced
+        r = super()._apply(fn, *a, **k)
+        self.invalidate()
+        return r
 
     def _pack(self, device):
-        key = (str(device), tuple(p._version for p in self.parameters()),
-               tuple(b._version for b in self.buffers()))
+        key = (str(device), _lib.tensor_versions(self))
         if self._packed is None or self._packed[0] != key:
             sd = {f"{self._prefix}.{k}": v for k, v in self.state_dict().items()}
             params, keep = weights.pack_tower(sd, self._prefix, self._names, self._n_num, device)
