@@ -31,7 +31,8 @@ NITER = 10
 MAX_POINTS_PER_CENTROID = 256
 SEED = 1234
 POOL_BYTES = 2 << 30           # candidate-pool workspace per query chunk
-GROUPED_MIN_QUERIES = 16       # batches at least this large scan list-major (every list read once per 64 queries)
+GROUPED_MIN_QUERIES = 16       # batches at least this large MAY scan list-major (every list read once per query tile) ...
+GROUPED_MIN_PAIRS_PER_LIST = 3.0   # ... if a probed list is shared by at least this many of the batch's queries on average
 QTILE = 64                     # queries per grouped-scan tile (ShapeIvf::BP) ...
 QTILE_SPARSE = 32              # ... or 32 (ShapeIvf32) when fewer than SPARSE_PAIRS_PER_LIST queries probe a list on average
 SPARSE_PAIRS_PER_LIST = 24
@@ -58,6 +59,17 @@ def _assign(x: torch.Tensor, cent: torch.Tensor) -> torch.Tensor:
                                      cent.stride(0), _lib.ptr(out), None, _lib.ptr(ws), ws.numel(),
                                      _lib.stream_ptr(x.device)))
     return out
+
+
+def use_grouped_scan(nq: int, nprobe: int, nlist: int) -> bool:
+    """List-major (grouped) scan or one workgroup set per (query, probe) pair?  The grouped scan reads a probed list once
+    per query tile, the pair scan once per probing query - but at the HBM rate whatever the lists' lengths (their rows are
+    split over workgroups), where the grouped kernel's (list, query tile, 256 rows) workgroups run ~3x slower than their
+    bytes on short or thinly shared lists (1M ads, nlist 4096, nprobe 64, 64 queries: 1.6 queries per probed list -
+    0.60 ms grouped, HBM time of the pairs' bytes 0.2).  So: grouped from GROUPED_MIN_QUERIES queries on AND only when
+    the batch's (query, probe) pairs outnumber the lists they can fall on GROUPED_MIN_PAIRS_PER_LIST to one."""
+    pairs = nq * nprobe
+    return nq >= GROUPED_MIN_QUERIES and pairs >= GROUPED_MIN_PAIRS_PER_LIST * min(nlist, pairs)
 
 
 def grouped_chunk_limit(nlist: int, nprobe: int) -> int:
@@ -177,7 +189,7 @@ class IVFState:
         n_pool = torch.empty((nq,), dtype=torch.int64, device=self.device)
         pool_ld = self.pool_rows_bound(nprobe)
         chunk = max(1, min(nq, 65535, POOL_BYTES // (pool_ld * 8)))
-        grouped = nq >= GROUPED_MIN_QUERIES
+        grouped = use_grouped_scan(nq, nprobe, self.nlist)
         qtile = QTILE_SPARSE if min(chunk, nq) * nprobe < SPARSE_PAIRS_PER_LIST * self.nlist else QTILE
         if grouped:
             chunk = min(chunk, grouped_chunk_limit(self.nlist, nprobe))

@@ -183,3 +183,15 @@ def test_stream_ptr_device_scope_is_restored_by_check(monkeypatch):
     _lib.stream_ptr(torch.device("cuda", 0))                 # already current: no switch, nothing to restore
     _lib.check(0)
     assert state["log"] == [3, 0]
+
+
+def test_ivf_scan_choice_by_pairs_per_list():
+    """amdrec.ivf.use_grouped_scan: list-major only for batches whose (query, probe) pairs share lists (>= 3 per list on
+    average, >= 16 queries); thinly shared or short lists take the pair scan, which runs at the HBM rate of its bytes."""
+    from amdrec import ivf
+    assert ivf.use_grouped_scan(512, 64, 4096)            # configs[4]: 8 pairs per list
+    assert ivf.use_grouped_scan(64, 10, 100)              # the reference's default index, 64 requests: 6.4 per list
+    assert not ivf.use_grouped_scan(64, 64, 4096)         # 4096 pairs on up to 4096 lists
+    assert not ivf.use_grouped_scan(8, 10, 100)           # below GROUPED_MIN_QUERIES
+    assert not ivf.use_grouped_scan(1, 10, 100)
+    assert ivf.use_grouped_scan(16, 16, 37)

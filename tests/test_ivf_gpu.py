@@ -217,7 +217,7 @@ def test_two_phase_grouped_scan_with_ties_at_tau(n, nlist, k, copies):
     from amdrec.index import FAISSIndex, flat_search
     from amdrec import ivf
     nq, nprobe = 24, 16
-    assert nq >= ivf.GROUPED_MIN_QUERIES and nprobe >= ivf.TWO_PHASE_MIN_PROBES
+    assert ivf.use_grouped_scan(nq, nprobe, nlist) and nprobe >= ivf.TWO_PHASE_MIN_PROBES
     base = _clustered(n // copies, 256, 12, 21)
     xb = np.concatenate([base] * copies)                        # copy j of row i at position j * (n // copies) + i
     xq = _clustered(nq, 256, 12, 22)
