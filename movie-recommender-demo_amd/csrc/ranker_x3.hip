@@ -1,7 +1,6 @@
 // The fp16x3 row-owner engine of amdrec_ranker_forward (kernel machinery and numerics: rowowner.hpp).
 //   ranker_x3_kernel : input rows (dense X or cached-projection gather) -> all phases of the chain -> logits
 //   amdrec_ranker_x3_prefix : debugging / test entry: run the first n phases on a dense X and return the rows
-#include <stdlib.h>
 #include "rowowner.hpp"
 #include "rowowner16.hpp"
 #include "rowowner16c.hpp"
@@ -112,10 +111,7 @@ static int x3_launch(const x3::Program& G, const x3::Input& in, long long rows, 
             else w += (double)P.n_tasks * (256.0 * 32.0 * P.n_steps + 64.0 * 32.0 * P.n_steps + 64.0);
         }
         ProfScope prof("ranker_colsplit16_x3", 2.0 * (double)rows * w, (double)rows * (1024.0 + 12.0), st);
-        static const int n_pre = [] {                  // AMDREC_X3C_PREFETCH=0: no prefetch workgroups (for A/B timing)
-            const char* e = getenv("AMDREC_X3C_PREFETCH");
-            return e ? atoi(e) : x3c::PREFETCH_WGS;
-        }();
+        const int n_pre = x3c::PREFETCH_WGS;           // (A/B against 0: profiles/r03_x3c_prefetch_ab.log)
         const int n_row_wgs = (int)((rows + x3c::ROWS_PER_WG - 1) / x3c::ROWS_PER_WG);
         hipLaunchKernelGGL(x3c::ranker_x3c_kernel, dim3((unsigned)(n_row_wgs + (n_pre > 0 ? n_pre : 0))), dim3(64 * x3c::WAVES),
                            x3c::LDS_BYTES, st, G, in, rows, n_row_wgs, x_out, ld_xout, logits, ld_logits);
