@@ -3,6 +3,9 @@
 // throughput shape), x3b4: 4 waves = 64 rows (one wave per SIMD: a pass of <= 16384 rows spreads over twice the CUs and a
 // wave has its SIMD to itself - 0.20 instead of 0.28 ms for one request's 500 rows, tools/x3_probe.hip).  No include guard.
 
+// (a step without stage 2 is passed the not-yet-written hidden planes by reference and never reads them)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized-const-reference"
 namespace amdrec {
 namespace AMDREC_X3B_NAMESPACE {
 
@@ -732,3 +735,4 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ranker_x3b_kernel(Program G, In
 
 }  // namespace AMDREC_X3B_NAMESPACE
 }  // namespace amdrec
+#pragma clang diagnostic pop
