@@ -53,6 +53,12 @@ def parse_args(argv=None):
     ap.add_argument("--nprobe", type=int, default=64, help="IVF probes per query (every rank scans its slice of each probed list)")
     ap.add_argument("--no-strict-fp32", action="store_true",
                     help="skip the second figure (`strict_fp32`: 5 steps with the ranker on the fp32-MFMA engine)")
+    ap.add_argument("--ranker-engine", choices=["default", "f16x3", "fp32", "bf16x6"], default="default",
+                    help="TransformerRanker.gemm_engine for the WHOLE run (default: the drop-in's default, f16x3); "
+                         "`fp32` = the strict fp32-MFMA engine as the headline (profiles/r04_bench_kernel_stats_fp32.csv)")
+    ap.add_argument("--user-batches", type=int, default=8,
+                    help="distinct seeded user batches rotated through the timed loop (a serving benchmark never sees the "
+                         "same users twice in a row); the one-batch replay is reported beside it as `same_batch`")
     ap.add_argument("--no-latency-sweep", action="store_true",
                     help="skip `e2e_latency_by_batch` (one recommend_device call at B = 1 / 8 / 64 / 512, N = 1 only)")
     ap.add_argument("--dry-run", action="store_true",
@@ -70,15 +76,17 @@ def launch_ranks(args, argv):
     (subprocess: fork + exec of a process that holds no HIP state), so nothing that owns a GPU context ever execs.
     stdout / stderr are inherited: rank 0's JSON line is this process's JSON line.  Exit code = the first failing
     rank's (the others are terminated by PID), 0 when every rank exits 0."""
-    import socket
     import subprocess
-    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    import tempfile
+    # Rendezvous of the self-launched world through a FILE store in a private temporary directory (init_method
+    # file://...): probing a free TCP port and closing the socket before the children bind it left a window in which
+    # another process could take the port and the run died in init_process_group (ADVICE r3).  Under torchrun the
+    # rendezvous is torchrun's (MASTER_ADDR / MASTER_PORT).
+    tmp = tempfile.mkdtemp(prefix="amdrec_bench_rdzv_")
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AMDREC_BENCH_SELF_LAUNCHED="1")
+                   AMDREC_BENCH_INIT_FILE=os.path.join(tmp, "store"), AMDREC_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this host driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
     rc = 0
@@ -94,6 +102,8 @@ def launch_ranks(args, argv):
                 for q in alive:                      # a rank died: the others would wait in a collective for ever
                     q.terminate()
         time.sleep(0.05)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     return rc
 
 
@@ -116,6 +126,8 @@ BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 X6_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6   # "x6" kernels: 6 bf16 MFMA products per fp32 multiply-add (gemm_core.hpp)
 X3_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 3   # "x3" kernel: 3 fp16 MFMA products per fp32 multiply-add (rowowner.hpp); fp16 rate == bf16 rate
 HBM_PEAK_GBS = 8000.0
+MIN_WARMUP = 20               # untimed steps before the timed region whatever --warmup says (the
+                              # power-limited ranker kernel is still settling its clock after 10 launches)
 
 
 def _t(sd):
@@ -311,6 +323,57 @@ def parity_check(ref, out, n_users):
             "top10_selection_exact": top10_ok, "top10_equal_to_oracle_frac": round(top10_same / max(n_users, 1), 4)}
 
 
+def _rendezvous():
+    """init_process_group keywords: the self-launched world meets through the launcher's file store, torchrun's through
+    MASTER_ADDR / MASTER_PORT (env://)."""
+    f = os.environ.get("AMDREC_BENCH_INIT_FILE")
+    if f:
+        return {"init_method": "file://" + f}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    return {}
+
+
+def roofline_block(name, p, run_tags, steps):
+    """The `roofline` object of one kernel tag from the library's per-launch HIP events (p = profile_report()[name] of a
+    timed region that recorded events around this tag only): achieved = algorithmic FLOPs per launch / average launch
+    time, against the peak of the engine the tag names (x3: fp16 MFMA / 3 products, x6: bf16 MFMA / 6, else fp32 MFMA)."""
+    avg_ms = p["total_ms"] / p["launches"]
+    achieved = p["flops"] / p["launches"] / (avg_ms * 1e-3) / 1e12
+    tr = pmc_traffic(name, run_tags)
+    x6 = name.endswith("_x6")       # fp32 GEMM computed as 6 bf16-MFMA products per MAC (exact 3-way split)
+    x3 = name.endswith("_x3")       # fp32 chain computed as 3 fp16-MFMA products per MAC (two-plane split)
+    peak = X3_PEAK_TFLOPS if x3 else (X6_PEAK_TFLOPS if x6 else FP32_PEAK_TFLOPS)
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "peak_note": ("fp32-equivalent FLOPs (2*M*N*K of every GEMM of the chain) against dense fp16 MFMA peak "
+                          f"/ 3 products = executed-MFMA utilisation; the fp32 MFMA peak is {FP32_PEAK_TFLOPS}; "
+                          "the peak is priced at 2.4 GHz - on realistic operands the chip holds ~2.0 GHz on this kernel "
+                          "(power-limited: profiles/r02_x3_cycle_stamps_and_dvfs.log), where the bound is ~694") if x3
+            else (("fp32-equivalent FLOPs (2*M*N*K) against dense bf16 MFMA peak / 6 products; "
+                   f"the fp32 MFMA peak is {FP32_PEAK_TFLOPS}") if x6 else "2*M*N*K against the fp32 MFMA peak"),
+            "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+            "traffic_source": tr["source"] if tr else None,
+            "alg_bytes_per_launch": round(p["bytes"] / p["launches"]),
+            "kernel": name, "launches_per_step": p["launches"] / steps,
+            "avg_launch_ms": round(avg_ms, 4),
+            "alg_gflop_per_launch": round(p["flops"] / p["launches"] / 1e9, 3)}
+
+
+def ranker_family(prof, steps):
+    """The ranker's GEMM tags of a fully event-timed pre-pass (strict fp32 engine: linear_* / residual_ln_* / cross_*):
+    per tag ms per step, TFLOP/s and the fraction of the fp32-MFMA peak, plus all of them together."""
+    fam = {k: v for k, v in prof.items() if k.startswith(("linear_", "residual_ln_", "cross_")) and v["total_ms"]}
+    out = {k: {"ms_per_step": round(v["total_ms"] / steps, 3), "launches_per_step": v["launches"] / steps,
+               "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2),
+               "frac_of_fp32_mfma_peak": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
+           for k, v in sorted(fam.items())}
+    if fam:
+        ms, fl = sum(v["total_ms"] for v in fam.values()), sum(v["flops"] for v in fam.values())
+        out["all"] = {"ms_per_step": round(ms / steps, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                      "frac_of_fp32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
+    return out
+
+
 def main():
     args = parse_args()
 
@@ -330,8 +393,7 @@ def main():
         if os.environ.get("AMDREC_BENCH_FAIL_RANK") == str(rank):       # test hook: a rank that dies before the rendezvous
             raise SystemExit(f"bench.py: rank {rank} failing on request (AMDREC_BENCH_FAIL_RANK)")
         if world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, **_rendezvous())
             seen = torch.ones(1, dtype=torch.int64)
             dist.all_reduce(seen)
             if int(seen.item()) != args.gpus or dist.get_world_size() != args.gpus:
@@ -350,11 +412,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, **_rendezvous())
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, **_rendezvous())
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
@@ -388,66 +449,97 @@ def main():
     ad_table = torch.from_numpy(synth.ad_features(ad, n_ads, seed=99)).to(device)   # replicated (160 MB / 1M)
     rec = AdRecommenderInference(two_tower_model=tt, transformer_ranker=rk, faiss_index=index,
                                  ad_features=ad_table)
+    if args.ranker_engine != "default":
+        rk.gemm_engine = args.ranker_engine
     B_global = USERS_PER_GPU * world
-    uc_np, un_np = synth.user_batch(user, nnum, B_global, seed=2024)
-    uc, un = torch.from_numpy(uc_np).to(device), torch.from_numpy(un_np).to(device)
+    # args.user_batches distinct seeded batches rotate through every loop below; batch 0 (seed 2024) is the one the CPU legs
+    # and the parity check use, and the rotation is arranged so that the LAST timed step runs batch 0: the output that is
+    # checked against the oracle is the timed region's own.
+    NB = max(1, args.user_batches)
+    batches_np = [synth.user_batch(user, nnum, B_global, seed=2024 + 7919 * j) for j in range(NB)]
+    batches = [(torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)) for a, b in batches_np]
+    uc_np, un_np = batches_np[0]
+    uc, un = batches[0]
 
     if world > 1:
-        from amdrec.sharded import ShardedRecommender
+        from amdrec.sharded import ShardedRecommender, StageTimer
         runner = ShardedRecommender(rec, rank, world, shard_offset=row0, shard_k=None if args.full_lists else "auto")
         # The drop-in's DEFAULT mode (verify=True): with short per-shard lists every step checks the merge's proof of
         # exactness (one 4-byte all-reduce + a host read) before it returns and repeats an unproven batch with full lists,
         # all inside the timed region.  The unverified mode (the caller checks inexact_count() once per reporting
         # interval) is timed separately below and reported as `no_verify`.
-        step = lambda: runner.recommend_device(uc, un, TOP_K, STAGE1_K)     # noqa: E731
+        run = lambda c, n, **kw: runner.recommend_device(c, n, TOP_K, STAGE1_K, **kw)      # noqa: E731
     else:
-        step = lambda: rec.recommend_device(uc, un, TOP_K, STAGE1_K)        # noqa: E731
+        run = lambda c, n, **kw: rec.recommend_device(c, n, TOP_K, STAGE1_K, **kw)         # noqa: E731
+
+    def rotating(steps):
+        """step i of `steps` -> batch (steps - 1 - i) % NB: distinct users step after step, batch 0 last"""
+        return lambda i, **kw: run(*batches[(steps - 1 - i) % NB], **kw)
+
+    same = lambda i, **kw: run(uc, un, **kw)                                               # noqa: E731
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
+    n_warm = max(args.warmup, MIN_WARMUP)
+    warm = rotating(n_warm)
+    for i in range(n_warm):
+        warm(i)
     barrier()
     # Per-kernel table: HIP events around EVERY tagged launch, in a pre-pass outside the timed region.  An event pair
     # costs the stream ~10 us of idle GPU per launch (kernel trace: 0.2 us between untimed kernels, 5-10 us around timed
     # ones), ~0.1 ms over the ~10 tagged launches of a step, so the timed region times only the dominant kernel.
     n_pre = max(1, min(5, args.steps))
-    _lib.profile_enable(True)
-    for _ in range(n_pre):
-        step()
-    torch.cuda.synchronize(device)
-    prof_all = _lib.profile_report()
-    dom_tag = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else ""
+
+    def prepass(fn, n):
+        _lib.profile_enable(True)
+        for i in range(n):
+            fn(i)
+        torch.cuda.synchronize(device)
+        rep = _lib.profile_report()
+        _lib.profile_enable(False)
+        return rep, (max(rep.items(), key=lambda kv: kv[1]["total_ms"])[0] if rep else "")
+
+    prof_all, dom_tag = prepass(rotating(n_pre), n_pre)
     stats0 = runner.short_list_stats() if world > 1 else None
 
-    def timed_region(fn, steps=None):
+    def timed_region(fn, steps=None, only=None):
         steps = args.steps if steps is None else steps
         barrier()
-        _lib.profile_enable(True, only=dom_tag)  # HIP events around the dominant kernel's launches, on the launch stream
+        _lib.profile_enable(True, only=dom_tag if only is None else only)  # HIP events around ONE kernel's launches, on the launch stream
         # per-step HIP events on the launch stream (torch's current stream IS the stream every kernel is enqueued on,
         # _lib.stream_ptr): median / p95 of the step time
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
         for i in range(steps):
             marks[i].record()
-            res = fn()
+            res = fn(i)
         marks[steps].record()
         barrier()
         dt_ = time.perf_counter() - t0
         ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
         prof_ = _lib.profile_report()
         _lib.profile_enable(False)
+        spread = None
         if world > 1:
-            tmax = torch.tensor([dt_], dtype=torch.float64, device="cpu" if rehearse else device)
+            cdev = "cpu" if rehearse else device
+            tmax = torch.tensor([dt_], dtype=torch.float64, device=cdev)
+            tmin = tmax.clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            spread = (float(tmin.item()), float(tmax.item()))
             dt_ = float(tmax.item())
-        return dt_, ms, prof_, res
+        return dt_, ms, prof_, res, spread
 
-    dt, step_ms, prof, out = timed_region(step)
-    short_lists, no_verify, exchange = None, None, None
+    dt, step_ms, prof, out, spread = timed_region(rotating(args.steps))
+    # the same region replaying ONE batch (rounds 1-3 timed this): every step gathers the same 256 000 rows of the ad
+    # projection cache and re-scores the same corpus rows, next to a 256 MB Infinity Cache
+    dt_same, _, _, _, _ = timed_region(same)
+    same_batch = {"value": round(B_global * args.steps / dt_same, 1), "ms_per_step": round(dt_same / args.steps * 1000, 3),
+                  "note": "one user batch replayed every step (what rounds 1-3 reported as `value`)"}
+    short_lists, no_verify, exchange, multi = None, None, None, None
     if world > 1:
         st = runner.short_list_stats()
         exchange = dict(runner.last_exchange)
@@ -459,63 +551,69 @@ def main():
         if runner.list_k(STAGE1_K) < STAGE1_K:
             # the same steps without the per-step check; a number is only reported if the proof held for every one of them
             runner.inexact_count()
-            dt2, ms2, _, _ = timed_region(lambda: runner.recommend_device(uc, un, TOP_K, STAGE1_K, verify=False))
+            rot = rotating(args.steps)
+            dt2, ms2, _, _, _ = timed_region(lambda i: rot(i, verify=False))
             bad = runner.inexact_count()                     # collective: the same value on every rank
             no_verify = {"value": round(B_global * args.steps / dt2, 1) if not bad else None,
                          "ms_per_step": round(dt2 / args.steps * 1000, 3), "unproven_queries": bad,
                          "note": "recommend_device(verify=False): the proof counter is read once after the region, not per step"}
+        # Self-diagnosis of the multi-GPU step (the driver's 8-GPU run is the first one on hardware): rank 0's per-stage
+        # times from a few EXTRA steps with HIP events at the stage boundaries (outside every timed region: an event
+        # pair idles the stream ~10 us), the slowest / fastest rank's wall time over the timed region, and what
+        # torch.distributed says the world is.
+        n_diag = max(1, min(5, args.steps))
+        runner.timer = StageTimer(device)
+        rot = rotating(n_diag)
+        for i in range(n_diag):
+            rot(i)
+        stages = runner.timer.report()
+        runner.timer = None
+        barrier()
+        multi = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                 "step_ms_max_over_ranks": round(spread[1] / args.steps * 1000, 3),
+                 "step_ms_min_over_ranks": round(spread[0] / args.steps * 1000, 3),
+                 "stages_ms_rank0": stages, "stages_steps": n_diag,
+                 "stages_note": "mean ms per step on rank 0, HIP events on the launch stream at the stage boundaries of "
+                                "ShardedRecommender._step (tower, search, pack, exchange = the one collective, merge, "
+                                "ranker, select); proof_wait = host wall time blocked on the proof's all-reduce while the "
+                                "ranker runs; measured in extra steps after the timed region",
+                 "verified": {"value": round(B_global * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1000, 3)},
+                 "unverified": no_verify}
     assert out["ad_ids"].shape[-1] == TOP_K
 
     # The same step with the ranker on the STRICT fp32-MFMA engine (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain, the
     # reference's arithmetic, transformer_ranker.py:355-378) - a second, labelled figure so that the headline's emulated
-    # fp32 (engine f16x3) is transparent.  5 timed steps after 2 warm-up steps; the default engine is restored afterwards.
+    # fp32 (engine f16x3) is transparent: args.steps timed steps (rotating batches) after its own warm-up, with its own
+    # roofline block (the fp32 engine's dominant kernel against the 157.3 TF fp32-MFMA peak) and per-kernel table.
     strict = None
-    if not args.no_strict_fp32:
+    if not args.no_strict_fp32 and rk.gemm_engine != "fp32":
         eng0 = rk.gemm_engine
         rows_step = USERS_PER_GPU * STAGE1_K
         rk.gemm_engine = "fp32"
         try:
-            for _ in range(2):
-                step()
-            n_strict = max(1, min(5, args.steps))
-            dts, mss, _, _ = timed_region(step, n_strict)
-            strict = {"value": round(B_global * n_strict / dts, 1), "unit": "recs/s", "ms_per_step": round(dts / n_strict * 1000, 3),
-                      "steps": n_strict, "engine": rk.gemm_engine_for(rows_step),
+            for i in range(3):
+                warm(i)
+            n_pre_s = max(1, min(3, args.steps))
+            prof_s, dom_s = prepass(rotating(n_pre_s), n_pre_s)
+            dts, mss, prof_dom_s, _, _ = timed_region(rotating(args.steps), only=dom_s)
+            strict = {"value": round(B_global * args.steps / dts, 1), "unit": "recs/s", "ms_per_step": round(dts / args.steps * 1000, 3),
+                      "step_ms_median": round(mss[len(mss) // 2], 3),
+                      "steps": args.steps, "engine": rk.gemm_engine_for(rows_step), "dtype": "f32",
+                      "roofline": roofline_block(dom_s, prof_dom_s.get(dom_s), list(prof_s), args.steps) if dom_s in prof_dom_s else None,
+                      "ranker_kernels": ranker_family(prof_s, n_pre_s),
                       "note": "same step, TransformerRanker.gemm_engine = 'fp32': every ranker GEMM on the fp32 MFMA "
                               "(exact fp32 products, fp32 accumulate); search and towers unchanged"}
         finally:
             rk.gemm_engine = eng0
-        step()                                          # re-pack the default engine (and its caches) before anything else
+        for i in range(3):                              # re-pack the default engine (and its caches) before anything else
+            warm(i)
         torch.cuda.synchronize(device)
 
     if rank == 0:
         ms_step = dt / args.steps * 1000
         value = B_global * args.steps / dt
-        # dominant kernel = the GEMM tag with the largest total time in the timed region
-        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"]) if prof else None
-        roofline = None
-        if dom:
-            name, p = dom
-            avg_ms = p["total_ms"] / p["launches"]
-            achieved = p["flops"] / p["launches"] / (avg_ms * 1e-3) / 1e12
-            tr = pmc_traffic(name, list(prof_all))
-            x6 = name.endswith("_x6")       # fp32 GEMM computed as 6 bf16-MFMA products per MAC (exact 3-way split)
-            x3 = name.endswith("_x3")       # fp32 chain computed as 3 fp16-MFMA products per MAC (two-plane split)
-            peak = X3_PEAK_TFLOPS if x3 else (X6_PEAK_TFLOPS if x6 else FP32_PEAK_TFLOPS)
-            roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
-                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                        "peak_note": ("fp32-equivalent FLOPs (2*M*N*K of every GEMM of the chain) against dense fp16 MFMA peak "
-                                      f"/ 3 products = executed-MFMA utilisation; the fp32 MFMA peak is {FP32_PEAK_TFLOPS}; "
-                                      "the peak is priced at 2.4 GHz - on realistic operands the chip holds ~2.0 GHz on this kernel "
-                                      "(power-limited: profiles/r02_x3_cycle_stamps_and_dvfs.log), where the bound is ~694") if x3
-                        else (("fp32-equivalent FLOPs (2*M*N*K) against dense bf16 MFMA peak / 6 products; "
-                               f"the fp32 MFMA peak is {FP32_PEAK_TFLOPS}") if x6 else "fp32 MFMA peak"),
-                        "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                        "traffic_source": tr["source"] if tr else None,
-                        "alg_bytes_per_launch": round(p["bytes"] / p["launches"]),
-                        "kernel": name, "launches_per_step": p["launches"] / args.steps,
-                        "avg_launch_ms": round(avg_ms, 4),
-                        "alg_gflop_per_launch": round(p["flops"] / p["launches"] / 1e9, 3)}
+        # dominant kernel = the tag with the largest total time in the pre-pass; its launches were timed in the region
+        roofline = roofline_block(dom_tag, prof.get(dom_tag), list(prof_all), args.steps) if prof.get(dom_tag) else None
         # the other kernels: from the n_pre fully timed steps that ran before the timed region
         kernels = {k: {"ms_per_step": round(v["total_ms"] / n_pre, 3),
                        "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None,
@@ -554,20 +652,28 @@ def main():
                       f"the {USERS_PER_GPU * STAGE1_K}-row pass of a step runs engine {eng_step}, a single request's "
                       f"{STAGE1_K}-row pass engine {rk.gemm_engine_for(STAGE1_K)}): "
                       + ("operands scaled by powers of two and split into 2 fp16 planes, 3 fp16-MFMA products per MAC, fp32 "
-                         "accumulate - an EMULATION of fp32 (logit error vs float64 = 2-3x the fp32-MFMA engine's, "
-                         "profiles/r03_accuracy.json; the strict fp32-MFMA figure is `strict_fp32`); " if eng_step == "f16x3" else
+                         "accumulate - an EMULATION of fp32: each operand keeps 22 significand bits (fp32: 24); error vs float64 "
+                         "= 2-3x the fp32-MFMA engine's on the LOGITS and up to 5-6x its worst element mid-chain "
+                         "(profiles/r04_accuracy.json, tests/test_x3_gpu.py); the strict fp32-MFMA figure is `strict_fp32`); "
+                         if eng_step == "f16x3" else
                          ("3 bf16 planes, 6 bf16-MFMA products per MAC, fp32 accumulate; " if eng_step == "bf16x6" else
                           "fp32 MFMA; "))
                       + "search: bf16-MFMA prefilter, fp32 re-score, certified exact; everything else fp32 MFMA / fp32 VALU")
         line = {"metric": "end-to-end recs/sec (1M ads d=256, top-500->10)" if default_cfg else
                           f"end-to-end recs/sec ({n_ads} ads d=256, {args.index}, top-500->10)", "value": round(value, 1),
                 "unit": "recs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "warmup_steps_run": n_warm + n_pre, "user_batches": NB, "same_batch": same_batch,
                 "ms_per_step": round(ms_step, 3),
                 "step_ms_median": round(step_ms[len(step_ms) // 2], 3),
                 "step_ms_p95": round(step_ms[min(len(step_ms) - 1, int(np.ceil(0.95 * len(step_ms))) - 1)], 3),
                 "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "arithmetic": arithmetic,
+                "vs_baseline": None,
+                # what the dominant stage computes in: fp32 operands and results, products on the fp16 / bf16 matrix pipe
+                "dtype": {"f16x3": "f32 (f16x3 emulation: 2 fp16 planes per operand, 3 fp16-MFMA products per MAC, fp32 accumulate)",
+                          "bf16x6": "f32 (bf16x6 emulation: 3 bf16 planes per operand, 6 bf16-MFMA products per MAC, fp32 accumulate)",
+                          }.get(eng_step, "f32"),
+                "compute_dtype": {"f16x3": "f16x3", "bf16x6": "bf16x6"}.get(eng_step, "f32"),
+                "data": "synthetic", "arithmetic": arithmetic,
                 "config": {"workload": ("configs[2]: 1M synthetic ads d=256, UserTower batch=512/GPU, "
                                         "exact IP top-500, TransformerRanker(256,8 heads,3 layers) on 500 cands, top-10")
                            if default_cfg else f"{n_ads} ads ({corpus_kind} corpus), index={args.index}"
@@ -588,6 +694,8 @@ def main():
                 "search": search}
         if latency is not None:
             line["e2e_latency_by_batch"] = latency
+        if multi is not None:                   # N > 1 only: the N = 1 line carries no such key
+            line["multi_gpu"] = multi
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -156,17 +156,37 @@ def profile_report():
                                    "flops": arr[i].flops, "bytes": arr[i].bytes} for i in range(n.value)}
 
 
+# Every registration of a Parameter / buffer / submodule on ANY nn.Module bumps this epoch (torch's global registration
+# hooks: `module.weight = nn.Parameter(...)`, `load_state_dict(assign=True)` on a child and parametrize all go through
+# register_parameter; assigning to an existing buffer name calls the buffer hooks).  One integer compare per forward tells
+# tensor_versions() whether some tensor OBJECT may have been replaced since it cached its list.
+_REG_EPOCH = [0]
+
+
+def _bump_registration_epoch(*_args):
+    _REG_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_registration_epoch)
+torch.nn.modules.module.register_module_buffer_registration_hook(_bump_registration_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_registration_epoch)
+
+
 def tensor_versions(module) -> tuple:
     """``_version`` of every parameter and buffer of ``module`` - the part of the drop-ins' packing-cache key that detects
     in-place weight updates (optimizer steps, ``copy_``).  The tensor list itself is cached on the module: walking
     ``parameters()`` on every call cost 0.1 ms per forward on the serving path (a fifth of a single request).  The cache is
-    dropped by the drop-ins' ``_apply`` / ``load_state_dict`` / ``invalidate``; code that REPLACES a Parameter object
-    (``module.weight = nn.Parameter(...)``) must call ``invalidate()``, as it must for any other change the versions cannot see."""
-    tl = module.__dict__.get("_amdrec_tensor_list")
-    if tl is None:
+    dropped by the drop-ins' ``_apply`` / ``load_state_dict`` / ``invalidate``, and re-walked whenever any Parameter, buffer
+    or submodule has been (re-)registered anywhere since it was taken (``_REG_EPOCH``): a REPLACED Parameter object is
+    seen - the new tensor's identity enters the key - and the replaced tensors are released."""
+    d = module.__dict__
+    tl = d.get("_amdrec_tensor_list")
+    if tl is None or d.get("_amdrec_tensor_epoch") != _REG_EPOCH[0]:
         tl = [*module.parameters(), *module.buffers()]
-        module.__dict__["_amdrec_tensor_list"] = tl
-    return tuple([t._version for t in tl])
+        d["_amdrec_tensor_list"] = tl
+        d["_amdrec_tensor_epoch"] = _REG_EPOCH[0]
+        d["_amdrec_tensor_ids"] = hash(tuple(id(t) for t in tl))
+    return (d["_amdrec_tensor_ids"], *[t._version for t in tl])
 
 
 def drop_tensor_list(module):

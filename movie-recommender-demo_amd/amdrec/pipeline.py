@@ -167,13 +167,15 @@ class AdRecommenderInference:
         return self.faiss_index.search_device(emb, stage1_k, normalize=False,                  # :230-232
                                               return_positions=True)
 
-    def _stage2(self, uc, un, cand_pos, top_k, check_indices, ids_are_positions=False):
+    def _stage2(self, uc, un, cand_pos, top_k, check_indices, ids_are_positions=False, mark=None):
         lib = _lib.load()
         B, stage1_k = cand_pos.shape
         if self.cache_ad_projection:
             self.transformer_ranker.ensure_ad_cache(self.ad_features)
         tasks, logits = self.transformer_ranker.score_candidates(uc, un, cand_pos, self.ad_features,  # :241-255
                                                                  check_indices=check_indices, raw=True)
+        if mark is not None:                     # amdrec.sharded.StageTimer: the ranker ends here, the selection follows
+            mark("ranker")
         ad_ids = torch.empty((B, top_k), dtype=torch.int64, device=uc.device)
         scores = torch.empty((len(tasks), B, top_k), dtype=torch.float32, device=uc.device)
         idx = self.faiss_index

@@ -101,6 +101,13 @@ class TransformerRanker(nn.Module):
     ENGINES = ("f16x3", "bf16x6", "fp32")
     SMALL_ROWS = 8192       # passes of at most this many rows run the fp32-MFMA small shapes (csrc/layers.hip)
 
+    def x3_fallback_reason(self):
+        """Why ``gemm_engine = "f16x3"`` would NOT run the row-owner kernel for these weights (None: it runs): the
+        engine is written for the reference's default architecture; anything else takes the generic tile GEMMs
+        (bf16x6 above SMALL_ROWS rows, fp32 MFMA below).  The first such pack also logs a warning - the fallback is
+        correct (golden-tested on the tutorial's architecture) but several times slower, and must not be silent."""
+        return weights.x3_ineligible_reason(self.state_dict(), self.fuse_attention)
+
     def gemm_engine_for(self, rows: int) -> str:
         """The engine a pass of ``rows`` rows actually runs on."""
         eng = self.gemm_engine
@@ -168,7 +175,13 @@ class TransformerRanker(nn.Module):
                _lib.tensor_versions(self))
         if self._packed is None or self._packed[0] != key:
             sd = self.state_dict()
-            x3 = self.gemm_engine == "f16x3" and weights.x3_eligible(sd, self.fuse_attention)
+            why = weights.x3_ineligible_reason(sd, self.fuse_attention) if self.gemm_engine == "f16x3" else None
+            x3 = self.gemm_engine == "f16x3" and why is None
+            if why is not None:
+                import warnings
+                warnings.warn(f"amdrec TransformerRanker: gemm_engine 'f16x3' is not available for these weights ({why}); "
+                              f"running the generic tile GEMMs (bf16x6 above {self.SMALL_ROWS} rows, fp32 MFMA below)",
+                              RuntimeWarning, stacklevel=3)
             params, keep, tasks = weights.pack_ranker(sd, self._user_names, self._ad_names,
                                                       self._n_num, device, fuse_attention=self.fuse_attention,
                                                       x6=self.gemm_engine == "bf16x6" or

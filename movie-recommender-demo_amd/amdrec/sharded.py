@@ -63,6 +63,49 @@ def packed_layout(n_users: int, k: int):
     return s_bytes, 2 * s_bytes
 
 
+STAGES = ("tower", "search", "pack", "exchange", "merge", "proof_wait", "ranker", "select")
+
+
+class StageTimer:
+    """Per-stage times of ShardedRecommender steps, so that a multi-GPU run localises its own problems (the first
+    8-GPU run is also the first debug run).  Device stages are bracketed by HIP events on the launch stream - a
+    collective issued through torch.distributed makes that stream wait for it, so the event behind it is the
+    collective's completion -, CPU engines (the gloo tests) by host clocks; ``proof_wait`` is host wall time (the
+    host blocks there while the ranker runs).  An event pair idles the stream ~10 us, so a timer is attached for a
+    few diagnostic steps, never inside a timed region.  ``report()`` -> mean ms per step and stage."""
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda"
+        self.marks, self.host, self.steps = [], {}, 0
+
+    def mark(self, name):
+        if self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, ev))
+        else:
+            import time
+            self.marks.append((name, time.perf_counter()))
+        if name == "start":
+            self.steps += 1
+
+    def add_host(self, name, seconds):
+        self.host[name] = self.host.get(name, 0.0) + seconds
+
+    def report(self):
+        if self.cuda:
+            torch.cuda.synchronize()
+        tot = {}
+        for (_, a), (nb, b) in zip(self.marks, self.marks[1:]):
+            if nb == "start":
+                continue
+            tot[nb] = tot.get(nb, 0.0) + (a.elapsed_time(b) if self.cuda else (b - a) * 1e3)
+        for k, v in self.host.items():
+            tot[k] = tot.get(k, 0.0) + v * 1e3
+        n = max(self.steps, 1)
+        return {k: round(tot.get(k, 0.0) / n, 4) for k in STAGES}
+
+
 class HipEngine:
     """The product engine: libamdrec kernels behind an AdRecommenderInference."""
 
@@ -70,8 +113,10 @@ class HipEngine:
         self.rec = rec
         self.shard_offset = int(shard_offset)
 
-    def local_search(self, uc, un, k):
+    def local_search(self, uc, un, k, mark=None):
         emb = self.rec.two_tower_model.user_tower.encode(uc, un, check_indices=False, renormalize=True)
+        if mark is not None:
+            mark("tower")
         pos, scores = self.rec.faiss_index.search_device(emb, k, normalize=False, return_positions=True,
                                                          pos_offset=self.shard_offset)
         return scores, pos
@@ -96,8 +141,8 @@ class HipEngine:
                                                      _lib.stream_ptr(dev)))
         return out_s, out_p
 
-    def rank(self, uc, un, cand_pos, top_k):
-        return self.rec._stage2(uc, un, cand_pos, top_k, False, ids_are_positions=True)
+    def rank(self, uc, un, cand_pos, top_k, mark=None):
+        return self.rec._stage2(uc, un, cand_pos, top_k, False, ids_are_positions=True, mark=mark)
 
 
 def share_ivf_centroids(index, train_rows, rank: int, world: int, group=None, src: int = 0):
@@ -186,6 +231,14 @@ class ShardedRecommender:
         self.last_exchange = None            # {"kind", "bytes_per_rank", "list_k"} of the most recent step
         self._side = None                    # side stream + pinned flag of the asynchronous proof read (_proof_begin)
         self._host_flag = None
+        self.timer = None                    # a StageTimer while a caller wants per-stage times (bench.py's N > 1 line)
+        import inspect
+        self._engine_marks = ("mark" in inspect.signature(self.engine.local_search).parameters
+                              and "mark" in inspect.signature(self.engine.rank).parameters)
+
+    def _mark(self, name):
+        if self.timer is not None:
+            self.timer.mark(name)
 
     def list_k(self, stage1_k: int) -> int:
         if self.shard_k is None or self.world <= 1:
@@ -227,7 +280,11 @@ class ShardedRecommender:
         # host until the ranker is done and exposes the next step's ~0.3 ms of launch work: 6 % in the 2-rank rehearsal.)
         proof = []
         out = self._step(user_categorical, user_numerical, top_k, stage1_k, kq, after_merge=lambda: proof.append(self._proof_begin()))
+        import time
+        t0 = time.perf_counter()
         bad = self._proof_end(proof[0])                                       # identical on every rank (all-reduce)
+        if self.timer is not None:
+            self.timer.add_host("proof_wait", time.perf_counter() - t0)
         B = int(user_categorical.shape[0])
         st = self.stats
         st["batches"] += 1
@@ -235,14 +292,19 @@ class ShardedRecommender:
         st["unproven_queries"] += bad
         self._recent = (self._recent + [1 if bad else 0])[-SHORT_LIST_WINDOW:]
         if bad:
-            # per-batch fallback: only this batch pays the second exchange; the decision to give short lists up for
-            # good needs more than an occasional unlucky query (every rank sees the same counts: same decision)
+            # per-batch fallback: only this batch pays the second exchange.  What it costs: the short-list step's ranker
+            # pass (already enqueued when the proof is read: ~2.7 ms of GPU time per 512 users) is discarded and the whole
+            # step, local search included, runs again with full lists - acceptable for the rare unlucky batch (6 sigma),
+            # which is why a corpus where it is NOT rare loses its short lists below.
             st["repeated_batches"] += 1
             out = self._step(user_categorical, user_numerical, top_k, stage1_k, stage1_k)
-            often = len(self._recent) >= 4 and sum(self._recent) > SHORT_LIST_MAX_REPEAT_FRAC * len(self._recent)
-            if bad > SHORT_LIST_MAX_FAIL_FRAC * B or often:
-                self.shard_k = None                                       # this corpus is not randomly sharded
-                st["switched_off"] = True
+        # The decision to give short lists up for good needs more than an occasional unlucky query; it is evaluated on
+        # EVERY verified batch (every rank sees the same counts: same decision), so the statistics and the decision stay
+        # consistent: a streak of repeats at or below the per-batch threshold switches them off as soon as the window says so.
+        often = len(self._recent) >= 4 and sum(self._recent) > SHORT_LIST_MAX_REPEAT_FRAC * len(self._recent)
+        if bad > SHORT_LIST_MAX_FAIL_FRAC * B or often:
+            self.shard_k = None                                           # this corpus is not randomly sharded
+            st["switched_off"] = True
         return out
 
     def _proof_begin(self):
@@ -294,7 +356,12 @@ class ShardedRecommender:
         """One exchange with lists of k entries per shard, merged to k_out candidates per user.  ``after_merge``: called once
         the merge is enqueued, before the ranker is (the proof read of the verified mode)."""
         B = uc.shape[0]
-        scores, pos = self.engine.local_search(uc, un, k)                     # [B,k] each
+        self._mark("start")
+        if self._engine_marks:
+            scores, pos = self.engine.local_search(uc, un, k, mark=self._mark)    # [B,k] each; marks "tower" inside
+        else:
+            scores, pos = self.engine.local_search(uc, un, k)
+        self._mark("search")
         q0, nq = user_slice(B, self.rank, self.world)
         inexact = None
         if k < k_out:
@@ -311,7 +378,9 @@ class ShardedRecommender:
             sv[:, :s_bytes].view(torch.float32).copy_(scores.reshape(self.world, nq * k))
             sv[:, s_bytes:].view(torch.int32).copy_(pos.reshape(self.world, nq * k))    # int64 -> int32 on the wire
             recv = torch.empty_like(send)
+            self._mark("pack")
             all_to_all_bytes(recv, send, self.group)                          # ONE collective per step
+            self._mark("exchange")
             self.last_exchange = {"kind": "all_to_all", "bytes_per_rank": int(send.numel()), "list_k": k}
             cand_scores, cand_pos = self._merge(recv, nq, k, 0, nq, k_out, inexact)
         else:
@@ -320,12 +389,19 @@ class ShardedRecommender:
             buf[:B * k * 4].view(torch.float32).copy_(scores.reshape(-1))
             buf[s_bytes:].view(torch.int32).copy_(pos.reshape(-1))        # int64 -> int32 on the wire
             gathered = torch.empty(chunk * self.world, dtype=torch.uint8, device=scores.device)
+            self._mark("pack")
             all_gather_bytes(gathered, buf, self.group)                       # ONE collective per step
+            self._mark("exchange")
             self.last_exchange = {"kind": "all_gather", "bytes_per_rank": int(buf.numel()), "list_k": k}
             cand_scores, cand_pos = self._merge(gathered, B, k, q0, nq, k_out, inexact)
+        self._mark("merge")
         if after_merge is not None:
             after_merge()
-        out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
+        if self._engine_marks:
+            out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k, mark=self._mark)   # marks "ranker" inside
+        else:
+            out = self.engine.rank(uc[q0:q0 + nq], un[q0:q0 + nq], cand_pos, top_k)
+        self._mark("select")
         out["candidate_scores"] = cand_scores
         out["user_offset"] = q0
         return out

@@ -400,29 +400,44 @@ def pack_tower(sd: Dict, prefix: str, feature_names: List[str], n_num: int, devi
     return p, pk
 
 
-def x3_eligible(sd: Dict, fuse_attention: bool) -> bool:
-    """The architecture the row-owner engine is written for (the reference's: d_model 256, heads 256 -> 64 -> 1)."""
-    if not fuse_attention or "feature_projection.weight" not in sd:
-        return False
+def x3_ineligible_reason(sd: Dict, fuse_attention: bool):
+    """None if the row-owner engine (f16x3) can run this state dict - the architecture it is written for is the
+    reference's default: d_model 256, heads 256 -> 64 -> 1 (transformer_ranker.py:213-224, :277-305) - else a short
+    reason.  Other architectures (e.g. tutorial.ipynb cell 19: d_model 128) run the generic tile GEMMs."""
+    if not fuse_attention:
+        return "fuse_attention is off (the engine needs the pre-multiplied W_ov)"
+    if "feature_projection.weight" not in sd:
+        return "no feature_projection in the state dict"
     dm = int(sd["feature_projection.weight"].shape[0])
     if dm != 256:
-        return False
+        return f"d_model {dm} != 256"
     l = 0
     while f"transformer_layers.{l}.norm1.weight" in sd:
-        if int(sd[f"transformer_layers.{l}.feed_forward.fc1.weight"].shape[0]) % 32:
-            return False
+        dff = int(sd[f"transformer_layers.{l}.feed_forward.fc1.weight"].shape[0])
+        if dff % 32:
+            return f"d_ff {dff} is not a multiple of 32"
         l += 1
     c = 0
     while f"feature_interaction.cross_weights.{c}" in sd:
         c += 1
     tasks = [t for t in TASKS if f"prediction_heads.{t}.0.weight" in sd]
-    if not tasks or 2 * l + c + 1 > 20 or len(tasks) > MAX_TASKS:
-        return False
+    if not tasks or len(tasks) > MAX_TASKS:
+        return f"{len(tasks)} prediction heads (1 .. {MAX_TASKS} supported)"
+    if 2 * l + c + 1 > 20:
+        return f"{2 * l + c + 1} phases (at most 20)"
     h1 = int(sd[f"prediction_heads.{tasks[0]}.0.weight"].shape[0])
     h2 = int(sd[f"prediction_heads.{tasks[0]}.3.weight"].shape[0])
+    if h1 % 32 or h2 != 64:
+        return f"head widths {h1} -> {h2} (multiple of 32 -> 64 supported)"
     dff = [int(sd[f"transformer_layers.{i}.feed_forward.fc1.weight"].shape[0]) for i in range(l)]
     n_par = sum(6 * 256 + d for d in dff) + 256 * c + len(tasks) * (h1 + 132)
-    return h1 % 32 == 0 and h2 == 64 and (n_par + 1023) // 1024 * 1024 <= X3_PARAM_FLOATS
+    if (n_par + 1023) // 1024 * 1024 > X3_PARAM_FLOATS:
+        return f"{n_par} bias / LayerNorm parameters exceed the kernel's LDS parameter area ({X3_PARAM_FLOATS})"
+    return None
+
+
+def x3_eligible(sd: Dict, fuse_attention: bool) -> bool:
+    return x3_ineligible_reason(sd, fuse_attention) is None
 
 
 def pack_ranker(sd: Dict, user_names: List[str], ad_names: List[str], n_num: int, device, ln_eps=1e-5,

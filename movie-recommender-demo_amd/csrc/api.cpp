@@ -31,6 +31,7 @@ std::vector<Tag> g_tags;
 std::vector<hipEvent_t> g_pool;
 std::string g_only;              // non-empty: only tags with this prefix are timed
 std::mutex g_mu;
+unsigned long long g_gen = 0;    // bumped (under g_mu) whenever the records' events go back to the pool
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e;
@@ -38,7 +39,7 @@ hipEvent_t get_event() {
     return e;
 }
 }  // namespace
-ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : end(nullptr), st(s) {
+ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : end(nullptr), st(s), gen(0) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_only.empty() && strncmp(tag, g_only.c_str(), g_only.size()) != 0) return;
@@ -50,10 +51,16 @@ ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s)
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
     end = r.b;
+    gen = g_gen;
 }
 ProfScope::~ProfScope() {
     if (end == nullptr) return;
-    (void)hipEventRecord(end, st);          // events are pooled, never destroyed: valid even if the table was reset meanwhile
+    // Events are pooled, never destroyed, so `end` is always a valid handle - but a reset / report from another thread
+    // between this scope's two ends has returned it to the pool, and get_event() may have handed it to a new scope:
+    // re-recording it would corrupt that scope's timing.  The generation says whether it is still ours.
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (gen != g_gen) return;
+    (void)hipEventRecord(end, st);
 }
 }  // namespace amdrec
 
@@ -62,6 +69,7 @@ extern "C" int amdrec_profile_enable(int on) {
     for (auto& r : amdrec::g_recs) { amdrec::g_pool.push_back(r.a); amdrec::g_pool.push_back(r.b); }
     amdrec::g_recs.clear();
     amdrec::g_tags.clear();
+    ++amdrec::g_gen;
     amdrec::g_prof_on = on != 0;
     return AMDREC_OK;
 }
@@ -84,6 +92,7 @@ extern "C" int amdrec_profile_report(amdrec_profile_entry* out, int max_entries,
         amdrec::g_pool.push_back(r.b);
     }
     amdrec::g_recs.clear();
+    ++amdrec::g_gen;
     int cnt = 0;
     for (auto& t : amdrec::g_tags) {
         if (cnt >= max_entries) break;

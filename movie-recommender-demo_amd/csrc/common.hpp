@@ -95,6 +95,8 @@ struct PerDeviceOnce {
 struct ProfScope {
     hipEvent_t end;          // nullptr: not timed.  The scope keeps the EVENT, not an index into the record table: another
     hipStream_t st;          // thread may reset the table (amdrec_profile_enable) between this scope's two ends
+    unsigned long long gen;  // generation of the record table the scope was opened in: a reset in between recycles its events,
+                             // which may by then belong to another scope - the end record is skipped in that case
     ProfScope(const char* tag, double flops, double bytes, hipStream_t st);
     ~ProfScope();
 };

@@ -234,10 +234,16 @@ __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
 __device__ __forceinline__ int select_sorted_keys(const unsigned long long* row, long long n, int k, int* hist, int* scratch,
                                                   unsigned long long* buf, int* count) {
     const int tid = threadIdx.x;
-    unsigned long long kstar = 0ull;          // gather everything by default (n <= k)
+    // A key of value 0 is an EMPTY slot, never a row (make_key of a NaN-free score is non-zero): the split select's partial
+    // lists are zero-padded, so a pool may hold S * k > k entries of which fewer than k are rows.  Empty slots are skipped
+    // by the histograms and by the gather (kstar >= 1); when fewer than k rows exist everything non-empty is gathered.
+    // (Round 3 counted the padding: the k-th largest of 300 rows + 7700 zeros was 0, the gather admitted all 8000 entries
+    // and kept an arbitrary 2048 of them - ADVICE r3.)
+    unsigned long long kstar = 1ull;          // gather every row by default (n <= k, or fewer than k non-empty keys)
     if (n > k) {
         uint32_t prefix = 0u, pmask = 0u;
         int rr = k;
+        bool all_rows = false;
         const int shifts[3] = {21, 10, 0};
         const int bits[3] = {11, 11, 10};
         for (int pass = 0; pass < 3; ++pass) {
@@ -245,11 +251,16 @@ __device__ __forceinline__ int select_sorted_keys(const unsigned long long* row,
             __syncthreads();
             const uint32_t bm = (1u << bits[pass]) - 1u;
             for (long long i = tid; i < n; i += 512) {
-                const uint32_t hi = (uint32_t)(row[i] >> 32);
-                if ((hi & pmask) == prefix) atomicAdd(&hist[(hi >> shifts[pass]) & bm], 1);
+                const unsigned long long key = row[i];
+                const uint32_t hi = (uint32_t)(key >> 32);
+                if (key != 0ull && (hi & pmask) == prefix) atomicAdd(&hist[(hi >> shifts[pass]) & bm], 1);
             }
             __syncthreads();
-            const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);   // always found: n > k >= rr
+            const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);   // -1: fewer than rr non-empty keys (pass 0 only)
+            if (bin < 0) {                                        // block-uniform: the pool holds fewer than k rows
+                all_rows = true;
+                break;
+            }
             prefix |= (uint32_t)bin << shifts[pass];
             pmask |= bm << shifts[pass];
             // keys at or above this bin's lower edge: the k - rr above the bin (rr = the k-th key's rank inside it) + the bin's
@@ -261,7 +272,8 @@ __device__ __forceinline__ int select_sorted_keys(const unsigned long long* row,
             __syncthreads();                                     // hist is cleared by the next pass
             if (at_or_above <= 2048) break;                      // block-uniform
         }
-        kstar = (unsigned long long)prefix << 32;      // every key at or above the k-th largest score's (partial) prefix
+        // every key at or above the k-th largest score's (partial) prefix
+        kstar = all_rows || prefix == 0u ? 1ull : (unsigned long long)prefix << 32;
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (tid == 0) *count = 0;
@@ -288,14 +300,14 @@ __device__ __forceinline__ int select_sorted_keys(const unsigned long long* row,
             const unsigned long long bm = (1ull << bits[pass]) - 1;
             for (long long i = tid; i < n; i += 512) {
                 const unsigned long long key = row[i];
-                if ((key & pmask) == prefix) atomicAdd(&hist[(int)((key >> shifts[pass]) & bm)], 1);
+                if (key != 0ull && (key & pmask) == prefix) atomicAdd(&hist[(int)((key >> shifts[pass]) & bm)], 1);
             }
             __syncthreads();
             const int bin = find_bin_desc<2048, 512>(hist, rr, scratch);
             prefix |= (unsigned long long)bin << shifts[pass];
             pmask |= bm << shifts[pass];
         }
-        kstar = prefix;
+        kstar = prefix ? prefix : 1ull;           // (more than 2048 non-empty keys were gathered: the k-th exists)
         __syncthreads();
     }
     const int have_all = *count < 2048 ? *count : 2048;

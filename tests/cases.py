@@ -14,7 +14,18 @@ def small_dims():
 CASES = {
     "demo": (synth.demo_dims, (1, 7, 64), 11),
     "ragged": (small_dims, (3, 33), 12),
+    # the reference's second usage example (tutorial.ipynb cells 10, 19): NOT the default architecture
+    "tutorial": (small_dims, (1, 7, 64), 13),
 }
+# constructor arguments that differ from the reference's defaults (two_tower_model.py:193-201, transformer_ranker.py:213-224)
+ARCH = {
+    "tutorial": {"tt": dict(embedding_dim=16, hidden_dims=[256, 128], output_dim=128),
+                 "rk": dict(embedding_dim=16, d_model=128, num_heads=4, num_layers=2, d_ff=512)},
+}
+
+
+def arch(name):
+    return ARCH.get(name, {"tt": {}, "rk": {}})
 CROSS = {"randn": 1.0, "scaled": 1.0 / 16}
 
 # Parity tolerances, stated once and used by every parity test:
@@ -27,14 +38,14 @@ TOPK_TAU = 1e-5          # near-tie band at the k-th score
 def two_tower_case(name):
     dims_fn, batches, seed = CASES[name]
     user, ad, nnum = dims_fn()
-    sd = synth.two_tower_state(user, ad, nnum, seed=seed)
+    sd = synth.two_tower_state(user, ad, nnum, seed=seed, **arch(name)["tt"])
     return user, ad, nnum, sd, batches
 
 
 def ranker_case(name, cross):
     dims_fn, batches, seed = CASES[name]
     user, ad, nnum = dims_fn()
-    sd = synth.ranker_state(user, ad, nnum, seed=seed + 1, cross_scale=CROSS[cross])
+    sd = synth.ranker_state(user, ad, nnum, seed=seed + 1, cross_scale=CROSS[cross], **arch(name)["rk"])
     return user, ad, nnum, sd, batches
 
 

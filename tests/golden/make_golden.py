@@ -46,17 +46,28 @@ CASES = {
     # name: (dims fn, batch sizes, seed)
     "demo": (synth.demo_dims, (1, 7, 64), 11),
     "ragged": (small_dims, (3, 33), 12),
+    # the reference's SECOND usage example (tutorial.ipynb cells 10 and 19): smaller constructor arguments than the
+    # defaults, on preprocessor-sized (ragged) feature dims
+    "tutorial": (small_dims, (1, 7, 64), 13),
+}
+# constructor arguments that differ from the reference's defaults (two_tower_model.py:193-201, transformer_ranker.py:213-224)
+ARCH = {
+    "tutorial": {"tt": dict(embedding_dim=16, hidden_dims=[256, 128], output_dim=128),
+                 "rk": dict(embedding_dim=16, d_model=128, num_heads=4, num_layers=2, d_ff=512)},
 }
 
 
-def main():
+def main(only=None):
     torch.set_num_threads(1)
     torch.manual_seed(0)
     for name, (dims_fn, batches, seed) in CASES.items():
+        if only and name not in only:
+            continue
         user_dims, ad_dims, nnum = dims_fn()
+        arch = ARCH.get(name, {"tt": {}, "rk": {}})
         # ---- two-tower -------------------------------------------------------------
-        sd = synth.two_tower_state(user_dims, ad_dims, nnum, seed=seed)
-        model = ref_tt.TwoTowerModel(dict(user_dims), dict(ad_dims), nnum)
+        sd = synth.two_tower_state(user_dims, ad_dims, nnum, seed=seed, **arch["tt"])
+        model = ref_tt.TwoTowerModel(dict(user_dims), dict(ad_dims), nnum, **arch["tt"])
         model.load_state_dict(to_torch(sd))
         model.eval()
         out = {"weights_sha256": synth.state_sha256(sd), "seed": seed}
@@ -79,8 +90,8 @@ def main():
         # ---- ranker ----------------------------------------------------------------
         for cs_name, cross_scale in (("randn", 1.0), ("scaled", 1.0 / 16)):
             sd = synth.ranker_state(user_dims, ad_dims, nnum, seed=seed + 1,
-                                    cross_scale=cross_scale)
-            model = ref_rk.TransformerRanker(dict(user_dims), dict(ad_dims), nnum)
+                                    cross_scale=cross_scale, **arch["rk"])
+            model = ref_rk.TransformerRanker(dict(user_dims), dict(ad_dims), nnum, **arch["rk"])
             model.load_state_dict(to_torch(sd))
             model.eval()
             out = {"weights_sha256": synth.state_sha256(sd), "seed": seed + 1,
@@ -102,4 +113,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])            # optional: case names to (re)generate; default all

@@ -195,3 +195,30 @@ def test_ivf_scan_choice_by_pairs_per_list():
     assert not ivf.use_grouped_scan(8, 10, 100)           # below GROUPED_MIN_QUERIES
     assert not ivf.use_grouped_scan(1, 10, 100)
     assert ivf.use_grouped_scan(16, 16, 37)
+
+
+def test_a_replaced_parameter_object_changes_the_packing_cache_key():
+    """the drop-ins key their packed weights on the tensors' `_version`s, read from a cached tensor list; a
+    Parameter REPLACED without `invalidate()` used to leave the stale list in place for ever (in-place updates of the new
+    tensor never reached the key).  The global registration epoch re-walks the list."""
+    from amdrec import _lib
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+    k0 = _lib.tensor_versions(m)
+    assert _lib.tensor_versions(m) == k0                      # stable while nothing changes
+    with torch.no_grad():
+        m[0].weight.add_(1.0)
+    k1 = _lib.tensor_versions(m)
+    assert k1 != k0                                           # in-place update: version bump
+    m[0].weight = torch.nn.Parameter(torch.zeros(4, 4))       # replaced object, no invalidate()
+    k2 = _lib.tensor_versions(m)
+    assert k2 != k1
+    with torch.no_grad():
+        m[0].weight.add_(1.0)                                 # ... and updates of the NEW tensor are seen
+    k3 = _lib.tensor_versions(m)
+    assert k3 != k2
+    m[1].running_mean = torch.ones(4)                         # a replaced buffer
+    assert _lib.tensor_versions(m) != k3
+    sd = {k: v.clone() + 1 for k, v in m.state_dict().items()}
+    k4 = _lib.tensor_versions(m)
+    m[0].load_state_dict({"weight": sd["0.weight"], "bias": sd["0.bias"]}, assign=True)   # assign=True on a child
+    assert _lib.tensor_versions(m) != k4

@@ -278,7 +278,10 @@ def test_coarse_key_table_gives_the_exact_search_probes(nlist, nprobe, nq):
 
 
 @pytest.mark.parametrize("nq,n,k,slices", [(1, 100_000, 500, 24), (3, 37_001, 500, 9), (2, 5_000, 500, 16), (5, 300, 500, 4),
-                                           (2, 70_000, 10, 64)])
+                                           (2, 70_000, 10, 64),
+                                           # fewer than k rows in a pool whose zero-padded partial lists exceed the
+                                           # 2048-key sort buffer (slices * k > 2048) - the padding must not count as keys
+                                           (2, 300, 500, 16), (1, 1500, 2048, 8)])
 def test_split_select_equals_the_single_workgroup_select(nq, n, k, slices):
     """amdrec_ivf_select_split (several workgroups per query, partial lists + a ticket) == amdrec_ivf_select, bit for bit:
     pools with duplicated scores (ties broken by position), ragged pool sizes, fewer keys than k, repeated calls on the same

@@ -19,7 +19,7 @@ def _t(sd):
 def _two_tower(name):
     from amdrec.towers import TwoTowerModel
     user, ad, nnum, sd, batches = cases.two_tower_case(name)
-    m = TwoTowerModel(dict(user), dict(ad), nnum)
+    m = TwoTowerModel(dict(user), dict(ad), nnum, **cases.arch(name)["tt"])
     m.load_state_dict(_t(sd))
     return m.cuda().eval(), sd, (user, ad, nnum), batches
 
@@ -27,7 +27,7 @@ def _two_tower(name):
 def _ranker(name, cross):
     from amdrec.ranker import TransformerRanker
     user, ad, nnum, sd, batches = cases.ranker_case(name, cross)
-    m = TransformerRanker(dict(user), dict(ad), nnum)
+    m = TransformerRanker(dict(user), dict(ad), nnum, **cases.arch(name)["rk"])
     m.load_state_dict(_t(sd))
     return m.cuda().eval(), sd, (user, ad, nnum), batches
 
@@ -48,7 +48,7 @@ def test_two_tower_matches_reference_golden(name):
         with torch.no_grad():
             ue, ae = m(uc, un, ac)
             ps = m.predict_scores(uc, un, ac)
-        assert ue.dtype == torch.float32 and ue.shape == (B, 256) and ue.is_cuda
+        assert ue.dtype == torch.float32 and ue.shape == (B, cases.arch(name)["tt"].get("output_dim", 256)) and ue.is_cuda
         assert np.abs(ue.cpu().numpy() - g[f"B{B}_user_emb"]).max() <= cases.EMB_ATOL
         assert np.abs(ae.cpu().numpy() - g[f"B{B}_ad_emb"]).max() <= cases.EMB_ATOL
         assert np.abs(ps.cpu().numpy() - g[f"B{B}_scores"]).max() <= cases.EMB_ATOL
@@ -114,8 +114,13 @@ def test_ranker_matches_reference_golden(name, cross, engine, accuracy):
     m, sd, _, batches = _ranker(name, cross)
     m.gemm_engine = engine
     g = load_golden(f"ranker_{name}_{cross}.npz")
+    # the row-owner engine is written for the reference's DEFAULT architecture (d_model 256); any other - the tutorial's
+    # d_model 128 / 4 heads / 2 layers / d_ff 512 - takes the generic tile GEMMs, and says so (the
+    # fallback must be visible, and it must have a golden)
+    x3 = engine == "f16x3" and name != "tutorial"
+    assert m.x3_fallback_reason() == (None if name != "tutorial" else "d_model 128 != 256")
     for B in batches:
-        assert m.gemm_engine_for(B) == ("f16x3" if engine == "f16x3" else "fp32")
+        assert m.gemm_engine_for(B) == ("f16x3" if x3 else "fp32")
         with torch.no_grad():
             pred = m(_cu(g[f"B{B}_user_cat"]), _cu(g[f"B{B}_ad_cat"]), _cu(g[f"B{B}_user_num"]))
         assert list(pred) == ["ctr", "engagement", "revenue"]
@@ -271,3 +276,34 @@ def test_checkpoint_dict_and_weight_update_invalidate_packing():
     a1 = m.get_ad_embeddings(_cu(ac)).cpu().numpy()
     assert np.abs(a1 - oracle.towers.ad_tower(sd2, ac)).max() <= cases.EMB_ATOL
     assert np.abs(a1 - a0).max() > 1e-3
+
+
+@pytest.mark.parametrize("rows", [300, 2000, 9001])
+def test_tutorial_architecture_batches_vs_oracle(rows, accuracy):
+    """the reference's second usage example (tutorial.ipynb cells 10, 19: towers [256, 128] -> 128,
+    ranker embedding 16 / d_model 128 / 4 heads / 2 layers / d_ff 512) beyond the golden batch sizes, on every generic path
+    those shapes take: tower GEMV / 16-row / tiled kernels are instantiated for the default shapes only, the ranker runs the
+    fp32-MFMA small shapes up to 8192 rows and the bf16x6 tiles beyond.  Against the oracle (pinned to the reference's own
+    outputs for this architecture by tests/test_oracle_golden.py)."""
+    import warnings
+    m, sd, (user, ad, nnum), _ = _two_tower("tutorial")
+    uc, un = synth.user_batch(user, nnum, rows, seed=rows)
+    ac = synth.ad_features(ad, rows, seed=rows + 1)
+    ue = m.get_user_embeddings(_cu(uc), _cu(un)).cpu().numpy()
+    ae = m.get_ad_embeddings(_cu(ac)).cpu().numpy()
+    assert ue.shape == (rows, 128)
+    assert np.abs(ue - oracle.towers.user_tower(sd, uc, un)).max() <= cases.EMB_ATOL
+    assert np.abs(ae - oracle.towers.ad_tower(sd, ac)).max() <= cases.EMB_ATOL
+    for cross in ("scaled", "randn"):
+        r, rsd, _, _ = _ranker("tutorial", cross)
+        assert r.gemm_engine == "f16x3" and r.gemm_engine_for(rows) == ("bf16x6" if rows > r.SMALL_ROWS else "fp32")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            pred = r(_cu(uc), _cu(ac), _cu(un))
+        assert any("not available for these weights (d_model 128 != 256)" in str(x.message) for x in w)   # not silent
+        ref = oracle.ranker.forward(rsd, uc, ac, un)
+        scale = cases.logit_scale(ref)
+        for t in ref:
+            ok, err = cases.logit_close(pred[t].cpu().numpy(), ref[t], cross, scale=scale)
+            accuracy(f"tutorial_{cross}/rows{rows}/{t}", r.gemm_engine_for(rows), err)
+            assert ok, (cross, rows, t, err)

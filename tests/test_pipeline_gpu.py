@@ -202,3 +202,55 @@ def test_index_save_load_roundtrip(tmp_path):
     a, b = rec.faiss_index.search(q, 50), idx2.search(q, 50)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert idx2.get_stats() == rec.faiss_index.get_stats()
+
+
+def test_tutorial_architecture_end_to_end_matches_oracle_pipeline():
+    """the whole path at the tutorial's architecture (tutorial.ipynb cells 10, 19, 26: Flat index over
+    128-dimensional embeddings, d_model-128 ranker) against oracle.pipeline - search kernels at d = 128, ad projection
+    cache at d_model 128, the generic ranker path, top-10."""
+    from amdrec.pipeline import AdRecommenderInference, build_faiss_index
+    from amdrec.ranker import TransformerRanker
+    from amdrec.towers import TwoTowerModel
+    user, ad, nnum = cases.small_dims()
+    a = cases.arch("tutorial")
+    tt_sd = synth.two_tower_state(user, ad, nnum, seed=61, **a["tt"])
+    rk_sd = synth.ranker_state(user, ad, nnum, seed=62, cross_scale=1.0 / 16, **a["rk"])
+    tt = TwoTowerModel(dict(user), dict(ad), nnum, **a["tt"])
+    tt.load_state_dict(_t(tt_sd))
+    rk = TransformerRanker(dict(user), dict(ad), nnum, **a["rk"])
+    rk.load_state_dict(_t(rk_sd))
+    n_ads, B, top_k, k1 = 20_000, 6, 10, 500
+    ad_table = synth.ad_features(ad, n_ads, seed=63)
+    index = build_faiss_index(tt, ad_table, index_type="Flat")
+    assert index.dimension == 128
+    rec = AdRecommenderInference(two_tower_model=tt, transformer_ranker=rk, faiss_index=index, ad_features=ad_table)
+    assert rk.x3_fallback_reason() == "d_model 128 != 256" and rk.gemm_engine_for(B * k1) == "fp32"
+    oidx = oracle.search.FlatIndex(128)
+    oidx.add(oracle.towers.ad_tower(tt_sd, ad_table))
+    uc, un = synth.user_batch(user, nnum, B, seed=64)
+    out = rec.recommend_device(torch.from_numpy(uc).cuda(), torch.from_numpy(un).cuda(), top_k, k1, check_indices=True)
+    ref = oracle.pipeline.recommend(tt_sd, rk_sd, oidx, ad_table, uc, un, top_k, k1)
+    cand, cs = out["candidate_ids"].cpu().numpy(), out["candidate_scores"].cpu().numpy()
+    logits = out["logits"].cpu().numpy().reshape(3, B, k1)
+    ids, sc = out["ad_ids"].cpu().numpy(), out["scores"].cpu().numpy()
+    for b in range(B):
+        r = ref[b]
+        oracle.search.check_topk(r["candidate_scores"][None], r["candidate_ids"][None], cs[b][None], cand[b][None],
+                                 tau=cases.TOPK_TAU, score_tol=2 * cases.SCORE_ATOL)
+        pos_ref = {int(i): j for j, i in enumerate(r["candidate_ids"])}
+        common = [j for j, i in enumerate(cand[b]) if int(i) in pos_ref]
+        assert len(common) >= k1 - 5
+        sel = np.array([pos_ref[int(cand[b][j])] for j in common])
+        for ti, t in enumerate(oracle.ranker.TASKS):
+            ok, err = cases.logit_close(logits[ti, b][common], r["logits"][t][sel], "scaled")
+            assert ok, (b, t, err)
+        # the GPU's winners are the winners of its own logits, and the oracle's unless the 10th place is a near-tie
+        own = cand[b][oracle.pipeline.select_top(logits[0, b], top_k)]
+        assert np.array_equal(own, ids[b])
+        miss = set(r["ad_ids"]) - set(ids[b].tolist())
+        if miss:
+            kth = np.sort(r["logits"]["ctr"])[::-1][top_k - 1]
+            for i in miss:
+                assert abs(r["logits"]["ctr"][pos_ref[i]] - kth) <= 2 * cases.LOGIT_STRICT_RTOL * max(1, abs(kth))
+        assert np.all((sc[:, b] > 0) & (sc[:, b] < 1))
+    # the reference API on top of it (dict of strings in, lists out) needs a preprocessor: covered by test_config0_gpu

@@ -454,3 +454,69 @@ def test_failed_centroid_training_raises_on_every_rank_instead_of_hanging():
         p.join(30)
         assert p.exitcode == 0
     assert res == {0: "ValueError", 1: "RuntimeError"}
+
+
+class MarkingEngine(OracleEngine):
+    """OracleEngine that accepts the StageTimer's mark callback like the HIP engine does (tower / ranker boundaries)."""
+
+    def local_search(self, uc, un, k, mark=None):
+        if mark is not None:
+            mark("tower")                               # (the oracle encodes and searches in one call: tower ~ 0 here)
+        return super().local_search(uc, un, k)
+
+    def rank(self, uc, un, cand_pos, top_k, mark=None):
+        out = super().rank(uc, un, cand_pos, top_k)
+        if mark is not None:
+            mark("ranker")
+        return out
+
+
+def _timer_worker(rank, world, port, q):
+    from amdrec.sharded import STAGES, StageTimer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tt_sd, rk_sd, ad_table, corpus, uc, un = _inputs(8)
+        per = (len(corpus) + world - 1) // world
+        lo, hi = rank * per, min(len(corpus), (rank + 1) * per)
+        reports = []
+        for eng_cls in (MarkingEngine, OracleEngine):    # an engine without the callback must still yield every key
+            sr = ShardedRecommender(None, rank, world, lo, engine=eng_cls(tt_sd, rk_sd, corpus[lo:hi], lo, ad_table), shard_k=40)
+            plain = sr.recommend_device(torch.from_numpy(uc), torch.from_numpy(un), TOPK, K1)
+            sr.timer = StageTimer("cpu")
+            for _ in range(2):
+                timed = sr.recommend_device(torch.from_numpy(uc), torch.from_numpy(un), TOPK, K1)
+            rep = sr.timer.report()
+            sr.timer = None
+            assert torch.equal(plain["ad_ids"], timed["ad_ids"])           # the timer changes nothing
+            reports.append((rep, sr.timer is None, tuple(STAGES), dist.get_backend(), dist.get_world_size()))
+        q.put((rank, reports))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_stage_timer_reports_every_stage_at_world_2():
+    """the multi-GPU bench line carries rank 0's per-stage times {tower, search, pack, exchange, merge,
+    proof_wait, ranker, select}; here the same StageTimer runs under gloo at world 2 on the CPU engines."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, reports in res:
+        for rep, detached, stages, backend, ws in reports:
+            assert set(rep) == set(stages) == {"tower", "search", "pack", "exchange", "merge", "proof_wait", "ranker", "select"}
+            assert all(v >= 0 for v in rep.values()) and detached
+            assert rep["search"] > 0 and rep["exchange"] > 0 and rep["merge"] > 0 and rep["proof_wait"] > 0
+            assert backend == "gloo" and ws == 2
+        assert reports[0][0]["ranker"] > 0               # the marking engine separates the ranker from the selection

@@ -171,6 +171,14 @@ def test_bench_rehearsal_two_ranks_on_one_gpu_prints_n_gpus_2():
     assert cfg["world"] == 2 and cfg["backend"] == "gloo" and cfg["exchange"] == "all_to_all"
     assert cfg["bytes_per_rank"] == 1024 * cfg["shard_lists"]["list_k_timed"] * 8
     assert cfg["users_per_step"] == 1024 and cfg["shard_lists"]["inexact_in_timed_steps"] == 0
+    # the N > 1 line localises its own problems
+    mg = doc["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["world_size"] == 2
+    assert set(mg["stages_ms_rank0"]) == {"tower", "search", "pack", "exchange", "merge", "proof_wait", "ranker", "select"}
+    assert all(mg["stages_ms_rank0"][k] > 0 for k in ("tower", "search", "exchange", "merge", "ranker", "select"))
+    assert mg["step_ms_max_over_ranks"] >= mg["step_ms_min_over_ranks"] > 0
+    assert mg["verified"]["value"] > 0 and "unverified" in mg
+    assert doc["user_batches"] == 8 and doc["same_batch"]["value"] > 0 and doc["warmup_steps_run"] >= 20
 
 
 def test_sharded_recommender_single_rank_rccl_matches_pipeline():
