@@ -116,36 +116,61 @@ struct EpiIvfKeys {
     __device__ void operator()(A& acc, float*) const {
         constexpr int TP = A::TP, TQ = A::TQ;
         const int lane = threadIdx.x & 63;
+        // Everything the 16 accumulator rows of a tile need from memory - the member's query, its threshold or pool offset -
+        // is fetched for all 16 FIRST (independent loads, in flight together), then the rows' positions; round 3 resolved
+        // pair_q -> tau / pair_p -> base row by row inside the store loop: 32-48 dependent round trips per workgroup,
+        // longer than the tile's MFMAs on short lists.
+        long long rowq[TQ], posq[TQ];
 #pragma unroll
-        for (int i = 0; i < TP; ++i)
+        for (int j = 0; j < TQ; ++j) {
+            rowq[j] = acc.q(j, lane);                             // row inside the list
+            posq[j] = rowq[j] < list_rows ? spos[rowq[j]] + pos_offset : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < TP; ++i) {
+            long long qv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long jj = acc.p(i, r, lane);          // member of the group (depends on the lane half)
-                if (jj >= g) continue;
-                const long long q = pair_q[jj];
-                if (tau != nullptr) {
-                    const float t = tau[q * ld_tau];
-                    unsigned long long* dst = keys + q * pool_ld;
+                qv[r] = jj < g ? pair_q[jj] : -1;
+            }
+            if (tau != nullptr) {
+                float tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tv[r] = qv[r] >= 0 ? tau[qv[r] * ld_tau] : __builtin_nanf("");   // NaN: no score passes
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
 #pragma unroll
                     for (int j = 0; j < TQ; ++j) {
-                        const long long row = acc.q(j, lane);
-                        if (row >= list_rows) continue;
                         float sc = acc.v[i][j][r];
                         if (!(sc == sc)) sc = -INFINITY;
-                        if (sc >= t) dst[atomicAdd(&fill[q], 1ull)] = make_key(sc, (uint32_t)(spos[row] + pos_offset));
+                        if (sc >= tv[r] && posq[j] >= 0)
+                            (keys + qv[r] * pool_ld)[atomicAdd(&fill[qv[r]], 1ull)] = make_key(sc, (uint32_t)posq[j]);
                     }
-                    continue;
                 }
-                unsigned long long* dst = keys + q * pool_ld + base[q * nprobe + pair_p[jj]];
+                continue;
+            }
+            long long off[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long jj = acc.p(i, r, lane);
+                off[r] = qv[r] >= 0 ? pair_p[jj] : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) off[r] = qv[r] >= 0 ? qv[r] * pool_ld + base[qv[r] * nprobe + off[r]] : -1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (off[r] < 0) continue;
+                unsigned long long* dst = keys + off[r];
 #pragma unroll
                 for (int j = 0; j < TQ; ++j) {
-                    const long long row = acc.q(j, lane);        // row inside the list
-                    if (row >= list_rows) continue;
+                    if (posq[j] < 0) continue;
                     float sc = acc.v[i][j][r];
                     if (!(sc == sc)) sc = -INFINITY;
-                    dst[row] = make_key(sc, (uint32_t)(spos[row] + pos_offset));
+                    dst[rowq[j]] = make_key(sc, (uint32_t)posq[j]);
                 }
             }
+        }
     }
 };
 
@@ -197,6 +222,10 @@ struct EpiCoarseKeys {
 using ShapeIvf = Shape<2, 2, 1, 4>;     // 64 queries x 256 list rows per workgroup
 using ShapeIvf32 = Shape<1, 4, 1, 2>;   // 32 queries x 256 list rows: for sparse groups (few probing queries per list: 512 x 64
                                         // probes over 4096 lists is 8 per list, a 64-query tile would be 12 % full)
+// SHORT lists (round 4): a rank of an 8-way sharded 10M index holds ~305 rows of each of the 4096 lists - two 256-row tiles
+// of which the second is 19 % full (68 % of the MFMAs multiply padding); 128-row tiles pad the same list to 384 rows.
+using ShapeIvfS = Shape<2, 2, 1, 2>;    // 64 queries x 128 list rows
+using ShapeIvf32S = Shape<1, 4, 1, 1>;  // 32 queries x 128 list rows
 
 template <class ShapeIvf>
 __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
@@ -207,10 +236,23 @@ __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long long y = blockIdx.y;
     if (y >= qt_prefix[nlist]) return;
-    int lo = 0, hi = nlist;                  // list l with qt_prefix[l] <= y < qt_prefix[l+1]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (qt_prefix[mid] <= y) lo = mid; else hi = mid;
+    // list l with qt_prefix[l] <= y < qt_prefix[l+1].  A binary search is log2(nlist) DEPENDENT global loads - 12 round trips
+    // at nlist 4096, ~10 us in front of a workgroup whose MFMAs take 14 (the per-rank shape of an 8-way sharded 10M index:
+    // 305-row lists, tools/shard_step_probe.py --index ivf) - so every wave searches 64-ary: the lanes probe 64 evenly
+    // spaced entries of the bracket at once, a ballot counts those at or below y (the prefix is non-decreasing): two or
+    // three round trips for any nlist up to 2^18.
+    int lo = 0, hi = nlist;
+    {
+        const int lane = threadIdx.x & 63;
+        while (hi - lo > 1) {                                                  // wave-uniform
+            const int step = (hi - lo + 63) >> 6;
+            const int idx = lo + lane * step;
+            const bool le = idx < hi && qt_prefix[idx] <= y;                   // lane 0 probes lo itself: always true
+            const int c = __builtin_popcountll(__ballot(le));                  // >= 1
+            const int nlo = lo + (c - 1) * step;
+            hi = nlo + step < hi ? nlo + step : hi;
+            lo = nlo;
+        }
     }
     const int l = lo;
     const long long r0 = list_off[l], len = list_off[l + 1] - r0;
@@ -673,20 +715,22 @@ extern "C" int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, 
     REQUIRE(ld % 4 == 0 && ld >= dim && ld_queries >= dim && ld_queries % 4 == 0, "bad leading dimension");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
-    if (qtile == 64)
-        e = launch_group_scan<ShapeIvf>("ivf_scan_grouped_64x256", lists, ld, dim, (const long long*)row_pos,
-                                        (const long long*)list_off, nlist, max_list_rows, queries, ld_queries,
-                                        (const long long*)group_off, (const long long*)qtile_prefix, qtile_bound,
-                                        (const long long*)pair_query, (const long long*)pair_probe, (const long long*)pool_base,
-                                        nprobe, (unsigned long long*)pool_keys, pool_ld, pos_offset, tau, (long long)ld_tau,
-                                        (unsigned long long*)pool_fill, st);
-    else
-        e = launch_group_scan<ShapeIvf32>("ivf_scan_grouped_32x256", lists, ld, dim, (const long long*)row_pos,
-                                          (const long long*)list_off, nlist, max_list_rows, queries, ld_queries,
-                                          (const long long*)group_off, (const long long*)qtile_prefix, qtile_bound,
-                                          (const long long*)pair_query, (const long long*)pair_probe, (const long long*)pool_base,
-                                          nprobe, (unsigned long long*)pool_keys, pool_ld, pos_offset, tau, (long long)ld_tau,
-                                        (unsigned long long*)pool_fill, st);
+    // row tile: 128 rows when even the longest list is short (the tile count of a launch is sized by it), else 256.
+    // AMDREC_IVF_SHORT_ROWS overrides the limit (0: never) for A/B runs (tools/shard_step_probe.py --index ivf).
+    static const long long short_rows = [] {
+        const char* v = getenv("AMDREC_IVF_SHORT_ROWS");
+        return v ? atoll(v) : 1536ll;
+    }();
+    const bool short_lists = max_list_rows <= short_rows;
+#define AMDREC_IVF_GROUP_SCAN(SHAPE, TAG)                                                                                       \
+    launch_group_scan<SHAPE>(TAG, lists, ld, dim, (const long long*)row_pos, (const long long*)list_off, nlist, max_list_rows, \
+                             queries, ld_queries, (const long long*)group_off, (const long long*)qtile_prefix, qtile_bound,    \
+                             (const long long*)pair_query, (const long long*)pair_probe, (const long long*)pool_base, nprobe,  \
+                             (unsigned long long*)pool_keys, pool_ld, pos_offset, tau, (long long)ld_tau,                      \
+                             (unsigned long long*)pool_fill, st)
+    if (qtile == 64) e = short_lists ? AMDREC_IVF_GROUP_SCAN(ShapeIvfS, "ivf_scan_grouped_64x128") : AMDREC_IVF_GROUP_SCAN(ShapeIvf, "ivf_scan_grouped_64x256");
+    else             e = short_lists ? AMDREC_IVF_GROUP_SCAN(ShapeIvf32S, "ivf_scan_grouped_32x128") : AMDREC_IVF_GROUP_SCAN(ShapeIvf32, "ivf_scan_grouped_32x256");
+#undef AMDREC_IVF_GROUP_SCAN
     HIP_TRY(e);
     return AMDREC_OK;
 }

@@ -414,6 +414,15 @@ __device__ __forceinline__ float wave_tau(const float* row, long long n, int r, 
     return __uint_as_float(b);
 }
 
+// Round-4 switches of the corpus pass (bits of AMDREC_SCAN_OPT; same-box A/Bs: tools/scan_ab.sh, profiles/r04_scan_*):
+//   1  j-major MFMA order with the threshold scan of the PREVIOUS (32 rows x 32 queries) accumulator interleaved between the
+//      MFMAs of the current one: the scan (and its hit path) used to run after a quarter's last MFMA with the matrix pipe
+//      idle - and both waves of a SIMD reach that point together, the tile barrier keeps them in step.  Costs a second
+//      read of every A fragment (once per query tile); no extra registers (the two accumulators ping-pong).
+#ifndef AMDREC_SCAN_OPT
+#define AMDREC_SCAN_OPT 0
+#endif
+constexpr int SCAN_OPT = AMDREC_SCAN_OPT;
 constexpr int SCAN_ROWS = 128;          // corpus rows per LDS tile
 constexpr int SCAN_WHITS = 128;         // hit-list entries per wave and tile (expected ~11; overflow -> direct append)
 constexpr int SCAN_QGROUP = 512;        // queries per workgroup (8 waves x 64)
@@ -424,6 +433,15 @@ constexpr int SCAN_HIT_BYTES = 2 * 8 * SCAN_WHITS * 12;   // [2 lists][8 waves] 
 // and the tile ring are disjoint and a wave's LDS operations execute in order, so no wait is needed.
 __device__ __forceinline__ void lds_store_hit_opaque(uint32_t key_addr, unsigned long long key, uint32_t q_addr, int q) {
     asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(key_addr), "v"(key), "v"(q_addr), "v"(q) : "memory");
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): an index walk whose indices are constants in the body
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
 }
 
 template <int KS>                       // KS = dim / 16 in {2, 4, 8, 16}
@@ -578,6 +596,62 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
             }
     };
 
+    // SCAN_OPT & 1.  The threshold test of ONE 4-element group of accumulator `p` (rows prow + e + 8 g of query tile j).
+    auto scan_group = [&](auto full_tag, const f32x16& p, auto g_tag, float tqj, int qj0, int prow, uint32_t list_addr, int& wcount) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int g = decltype(g_tag)::value;
+        const float m4 = fmaxf(fmaxf(p[4 * g], p[4 * g + 1]), fmaxf(p[4 * g + 2], p[4 * g + 3]));
+        if (__builtin_expect(__ballot(m4 >= tqj) == 0ull, 1)) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sc = p[4 * g + e];
+            const int pr = prow + e + 8 * g;
+            const bool hit = sc >= tqj && (FULL || pr < nrows_i);
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {                                            // wave-uniform
+                if (hit) {
+                    const int q = qj0 + frow;
+                    const unsigned long long key = make_key(sc, (uint32_t)pr);
+                    const int slot = wcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (slot < SCAN_WHITS)
+                        lds_store_hit_opaque(list_addr + slot * 8, key, list_addr + SCAN_WHITS * 8 + slot * 4, q);
+                    else append(q, key);
+                }
+                wcount += __builtin_popcountll(mask);
+            }
+        }
+    };
+    // One unit = 32 corpus rows x query tile J: the K loop into `cur`, with the four group tests of the previous unit's
+    // accumulator `prv` placed behind MFMAs KS/4 - 1, 2 KS/4 - 1, ... (each test - three max, a compare, a ballot - runs in
+    // the shadow of the MFMA in front of it; the wave is back at the next, dependent MFMA before that one has finished).
+    auto chain_scan = [&](auto j_tag, auto scan_tag, auto full_tag, const unsigned char* lb, int G, f32x16& cur,
+                          const f32x16& prv, float tprv, int qprv0, int prow_prv, uint32_t list_addr, int& wcount) {
+        constexpr int J = decltype(j_tag)::value;
+        constexpr bool SCAN = decltype(scan_tag)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+        bf16x8 a[AHEAD];
+#pragma unroll
+        for (int s_ = 0; s_ < AHEAD; ++s_) a[s_] = *reinterpret_cast<const bf16x8*>(lb + ((32 * s_) ^ G));
+        // (a compile-time index walk: with a `#pragma unroll` loop the compiler kept the K loop rolled around the group tests'
+        //  branches and indexed the query fragments dynamically - 512 bytes of scratch per lane)
+        static_for<KS>([&](auto s_tag) {
+            constexpr int s_ = decltype(s_tag)::value;
+            const bf16x8 c = a[s_ % AHEAD];
+            if constexpr (s_ + AHEAD < KS) a[s_ % AHEAD] = *reinterpret_cast<const bf16x8*>(lb + ((32 * (s_ + AHEAD)) ^ G));
+            cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c, qf[J][s_], cur, 0, 0, 0);
+            if constexpr (SCAN) {
+                static_for<(4 * (s_ + 1)) / KS - (4 * s_) / KS>([&](auto g_tag) {
+                    constexpr int g = (4 * s_) / KS + decltype(g_tag)::value;
+                    __builtin_amdgcn_sched_barrier(0);             // the test stays BEHIND this MFMA (and in front of the next)
+                    scan_group(full_tag, prv, std::integral_constant<int, g>{}, tprv, qprv0, prow_prv, list_addr, wcount);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        });
+    };
+
     int t = bx;
     if (t < ntiles) dma(t, 0);
     // Thresholds.  Batches of <= 8 queries (gm != nullptr): no threshold launch - while the first tile is in flight wave w
@@ -624,8 +698,35 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
             const uint32_t list_addr =
                 (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)(hitbase + buf * LIST_STRIDE);
             const bool full = (long long)(t + 1) * SCAN_ROWS <= nrows;
+            using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>;
+            if ((SCAN_OPT & 1) && second) {
+                // units (rq, j = 0), (rq, 1), (rq + 1, 0) ...: accumulators acc0 / acc1 ping-pong, each unit's MFMAs carry the
+                // threshold scan of the unit before it; the tile's last unit is scanned on its own
+                f32x16 acc0, acc1;
+                const int qa = q0, qb = q0 + 32;
+                auto tile_units = [&](auto full_tag) {
+                    asm volatile("" : "+v"(G));
+                    chain_scan(I0{}, std::false_type{}, full_tag, lb + rq_begin * 32 * CPR * 16, G, acc0, acc1, 0.f, 0, 0,
+                               list_addr, wcount);
+#pragma unroll 1
+                    for (int rq = rq_begin; rq < rq_end; ++rq) {
+                        asm volatile("" : "+v"(G));
+                        const int prow = t * SCAN_ROWS + rq * 32 + 4 * fh;
+                        const unsigned char* lq = lb + rq * 32 * CPR * 16;
+                        chain_scan(I1{}, std::true_type{}, full_tag, lq, G, acc1, acc0, tq[0], qa, prow, list_addr, wcount);
+                        if (rq + 1 < rq_end) {
+                            chain_scan(I0{}, std::true_type{}, full_tag, lq + 32 * CPR * 16, G, acc0, acc1, tq[1], qb, prow,
+                                       list_addr, wcount);
+                        } else {
+                            static_for<4>([&](auto g_tag) { scan_group(full_tag, acc1, g_tag, tq[1], qb, prow, list_addr, wcount); });
+                        }
+                    }
+                };
+                if (full) tile_units(std::true_type{});
+                else tile_units(std::false_type{});
+            } else
 #pragma unroll 1
             for (int rq = rq_begin; rq < rq_end; ++rq) {
                 asm volatile("" : "+v"(G));

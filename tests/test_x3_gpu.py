@@ -80,14 +80,22 @@ def test_every_prefix_of_the_chain_matches_float64(cross, rows, accuracy):
         if n < n_total:
             ref = truth[n - 1]
             scale = np.abs(ref).max(axis=1, keepdims=True)            # per-row magnitude
-            err = float((np.abs(x - ref) / scale).max())
-            err32 = float((np.abs(f32[n - 1] - ref) / scale).max())   # the numpy fp32 evaluation of the same prefix
+            d, d32 = (x - ref) / scale, (f32[n - 1] - ref) / scale    # the engine's / the numpy fp32 evaluation's error
+            err, err32 = float(np.abs(d).max()), float(np.abs(d32).max())
+            rms, rms32 = float(np.sqrt(np.mean(d * d))), float(np.sqrt(np.mean(d32 * d32)))
             accuracy(f"x3_prefix/demo_{cross}/rows{rows}/{names[n - 1]}", f"f16x3/{VARIANT}", err / max(err32, 1e-30),
-                     rel_err_vs_float64=err, numpy_fp32_rel_err_vs_float64=err32)
+                     rel_err_vs_float64=err, numpy_fp32_rel_err_vs_float64=err32, rms_ratio=rms / max(rms32, 1e-30),
+                     rms_rel_err_vs_float64=rms, numpy_fp32_rms_rel_err_vs_float64=rms32)
             assert np.isfinite(x).all(), names[n - 1]
-            # worst recorded ratio 5.35 (L2.ffn_ln2, 16-row kernel, profiles/r02_accuracy.json): the bound is 6x with NO
-            # additive slack (the old `4x + 2e-6` passed only through its additive term)
-            assert err <= 6 * err32, (names[n - 1], err, err32)
+            # Mid-chain error of the emulation against the numpy fp32 evaluation of the same prefix, both measured against
+            # float64.  What the arithmetic allows: a MAC of the engine carries three terms of up to 2^-22 (the two operands'
+            # split errors and the dropped l*l product) = 12 * 2^-24 where an fp32 fma chain carries two roundings = 2 * 2^-24,
+            # i.e. a ratio of the BOUNDS of 6.  The RMS over the ~110k elements of a phase is the stable statistic and is
+            # held to 4x; the ratio of the two MAXIMA is noisy (the fp32 evaluation's realised maximum moves by +-30 % with
+            # the seed and sits well under its own bound) and is held to 8x, not to the 6x that round 3 had fitted to a
+            # recorded worst of 5.61 ("a bound fitted to the observation").
+            assert rms <= 4 * rms32, (names[n - 1], rms, rms32)
+            assert err <= 8 * err32, (names[n - 1], err, err32)
         else:
             scale = cases.logit_scale(truth[-1])
             for ti, t in enumerate(oracle.ranker.TASKS):

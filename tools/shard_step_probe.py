@@ -1,7 +1,10 @@
 """Dev tool: the COMPUTE of one rank's step at the weak-scaling shape of a G-rank run, on one GPU, without the collective:
 tower for the global batch (512 G users) -> search of a 1M/G-row shard with short lists -> pack -> merge of G lists (the
 rank's own list replicated at shifted positions stands in for the peers') -> ranker for the rank's 512 users -> top-10.
-usage: python tools/shard_step_probe.py G [reps]"""
+usage: python tools/shard_step_probe.py G [reps] [--index ivf [--ads N] [--nlist L] [--nprobe P]]
+--index ivf: configs[4] at the shape a rank of G sees - a (N / G)-row shard of the clustered N-ad corpus (default 10M) filed
+under ONE coarse quantizer of nlist centroids (default 4096, trained on this shard as rank 0 would), 512 G queries, nprobe 64,
+short per-shard lists; prints the search's per-kernel breakdown and the list scan's bytes against HBM."""
 import os
 import sys
 
@@ -15,15 +18,31 @@ from amdrec.index import FAISSIndex  # noqa: E402
 from amdrec.pipeline import AdRecommenderInference  # noqa: E402
 from amdrec.sharded import HipEngine, packed_layout, short_list_k  # noqa: E402
 
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+import argparse  # noqa: E402
+ap = argparse.ArgumentParser()
+ap.add_argument("G", type=int, nargs="?", default=8)
+ap.add_argument("reps", type=int, nargs="?", default=10)
+ap.add_argument("--index", choices=["flat", "ivf"], default="flat")
+ap.add_argument("--ads", type=int, default=None)
+ap.add_argument("--nlist", type=int, default=4096)
+ap.add_argument("--nprobe", type=int, default=64)
+A = ap.parse_args()
+G, reps = A.G, A.reps
 dev = torch.device("cuda", 0)
 tt, rk, _, dims = bench.build_models(dev)
 user, ad, nnum = dims
-rows = bench.N_ADS // G
-index = FAISSIndex(bench.DIM, index_type="Flat", device=dev)
-index.add(bench.device_corpus(bench.N_ADS, bench.DIM, dev, row0=0, rows=rows))
-ad_table = torch.from_numpy(synth.ad_features(ad, bench.N_ADS, seed=99)).to(dev)
+n_ads = A.ads or (10_000_000 if A.index == "ivf" else bench.N_ADS)
+rows = n_ads // G
+if A.index == "ivf":
+    shard = bench.device_corpus(n_ads, bench.DIM, dev, row0=0, rows=rows, kind="clustered")
+    index = FAISSIndex(bench.DIM, index_type="IVF", nlist=A.nlist, nprobe=A.nprobe, device=dev)
+    index.train(shard)                                   # rank 0 trains on its shard; the peers would receive the centroids
+    index.add(shard)
+    del shard
+else:
+    index = FAISSIndex(bench.DIM, index_type="Flat", device=dev)
+    index.add(bench.device_corpus(n_ads, bench.DIM, dev, row0=0, rows=rows))
+ad_table = torch.from_numpy(synth.ad_features(ad, rows * G if A.index == "ivf" else bench.N_ADS, seed=99)).to(dev)
 rec = AdRecommenderInference(two_tower_model=tt, transformer_ranker=rk, faiss_index=index, ad_features=ad_table)
 B = 512 * G
 uc, un = synth.user_batch(user, nnum, B, seed=2024)
@@ -59,4 +78,39 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"G={G} list_k={kq} per-rank compute {ms:.3f} ms/step ({2 * G - 2} stand-in copies included) -> {512 * G / ms * 1e3:.0f} recs/s if the exchange were free")
+print(f"G={G} index={A.index} ads={n_ads} list_k={kq} per-rank compute {ms:.3f} ms/step ({2 * G - 2} stand-in copies included) -> {512 * G / ms * 1e3:.0f} recs/s if the exchange were free")
+# the search alone, whole call and per kernel
+from amdrec import _lib  # noqa: E402
+emb = rec.two_tower_model.user_tower.encode(uc, un, check_indices=False, renormalize=True)
+for _ in range(3):
+    index.search_device(emb, kq, normalize=False, return_positions=True)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(reps):
+    index.search_device(emb, kq, normalize=False, return_positions=True)
+e1.record()
+torch.cuda.synchronize()
+sms = e0.elapsed_time(e1) / reps
+_lib.profile_enable(True)
+for _ in range(reps):
+    index.search_device(emb, kq, normalize=False, return_positions=True)
+rep = _lib.profile_report()
+_lib.profile_enable(False)
+parts = " ".join(f"{k}={v['total_ms'] / reps:.4f}x{v['launches'] // reps}" for k, v in sorted(rep.items()))
+print(f"search of {B} queries x {rows} rows, k={kq}: {sms:.4f} ms  {parts}")
+if A.index == "ivf":
+    st = index._ivf
+    _, _, _, lens, max_len, _ = st._build_lists(index._xb, index._n)
+    cs = torch.empty((B, A.nprobe), dtype=torch.float32, device=dev)
+    probes = torch.empty((B, A.nprobe), dtype=torch.int64, device=dev)
+    from amdrec.index import flat_search  # noqa: E402
+    flat_search(st.centroids, st.nlist, emb.contiguous(), A.nprobe, cs, probes)
+    cnt = torch.bincount(probes.reshape(-1), minlength=st.nlist)
+    lf = lens.float()
+    once = int((lens * (cnt > 0)).sum().item()) * bench.DIM * 4            # every probed list once
+    for qt in (32, 64):
+        tiles = int((((cnt + qt - 1) // qt) * lens).sum().item()) * bench.DIM * 4
+        print(f"  list bytes if read once per {qt}-query tile: {tiles / 1e9:.3f} GB (once per probed list: {once / 1e9:.3f} GB)")
+    sc = sum(v["total_ms"] for k_, v in rep.items() if k_.startswith("ivf_scan")) / reps
+    print(f"  lists: len min/mean/max {int(lens.min())}/{lf.mean():.1f}/{max_len}; queries per probed list mean {cnt.float().mean():.1f} max {int(cnt.max())}; "
+          f"scan {sc:.4f} ms = {once / sc / 1e6 / 8000:.3f} of HBM peak on the once-per-list bytes")
