@@ -256,13 +256,16 @@ __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
     }
     const int l = lo;
     const long long r0 = list_off[l], len = list_off[l + 1] - r0;
-    const long long row0 = (long long)blockIdx.x * ShapeIvf::BQ;
-    if (row0 >= len) return;
+    if ((long long)blockIdx.x * ShapeIvf::BQ >= len) return;
     const long long g0 = goff[l], g = goff[l + 1] - g0;
     GatherRows lp{Q, pair_q + g0, g, (int)ldq, d};
     DenseRows lq{xs + r0 * ld, len, (int)ld, d, 30, 1ll << 30};
     EpiIvfKeys epi{spos + r0, len, pair_q + g0, pair_p + g0, g, base, nprobe, keys, pool_ld, pos_offset, tau, ld_tau, fill};
-    gemm_block<ShapeIvf>(lp, lq, epi, ksteps, (y - qt_prefix[l]) * ShapeIvf::BP, row0, smem);
+    const long long p0 = (y - qt_prefix[l]) * ShapeIvf::BP;
+    // gridDim.x workgroups share the list's row tiles (round 4: the host no longer launches one workgroup per row tile of
+    // the LONGEST list - on short lists three of four workgroups found no rows after paying for the tile search)
+    for (long long row0 = (long long)blockIdx.x * ShapeIvf::BQ; row0 < len; row0 += (long long)gridDim.x * ShapeIvf::BQ)
+        gemm_block<ShapeIvf>(lp, lq, epi, ksteps, p0, row0, smem);     // (ends behind a barrier: the staging area is free)
 }
 
 // k largest of keys[q][0..n_q) -> sorted (score desc, position asc); fewer than k -> padded (-inf, -1).
@@ -689,7 +692,16 @@ static hipError_t launch_group_scan(const char* tag, const float* lists, long lo
         if (e != hipSuccess) return e;
         attr_done.mark();
     }
-    const unsigned gx = (unsigned)((max_list_rows + S::BQ - 1) / S::BQ);
+    // workgroups per (list, query tile): an eighth of the LONGEST list's row tiles, each looping over its share of the list's
+    // tiles.  Round 3 launched one workgroup per row tile of the longest list for every (list, query tile): list lengths
+    // spread 0 .. 4x the mean, so three of four workgroups found no rows - after paying for the tile search - and at the
+    // per-rank shape of an 8-way sharded 10M index (305-row lists) 48 000 of 61 000 workgroups were empty: scan 1.82 ->
+    // 0.80 ms (profiles/r04_shard_ivf_g8_after.log).  AMDREC_IVF_GX overrides for A/B runs.
+    static const long long gx_env = [] { const char* v = getenv("AMDREC_IVF_GX"); return v ? atoll(v) : 0ll; }();
+    long long gxl = (max_list_rows + S::BQ - 1) / S::BQ;
+    const long long cap = gx_env > 0 ? gx_env : (gxl + 7) / 8;
+    if (gxl > cap) gxl = cap;
+    const unsigned gx = (unsigned)gxl;
     ProfScope prof(tag, 0.0, 0.0, st);
     hipLaunchKernelGGL(ivf_group_scan_kernel<S>, dim3(gx, (unsigned)qtile_bound), dim3(S::NT), S::LDS_BYTES, st, lists, ld, dim,
                        (dim + BK - 1) / BK, row_pos, list_off, queries, ld_queries, group_off, qtile_prefix, nlist, pair_query,

@@ -227,7 +227,7 @@ struct RingT {
         if (G == 0) next_chunk();
         // DBG & 64 (diagnostic build only): fragment reads for ONE group in four - the LDS -> VGPR traffic a kernel would
         // have in which a fragment set feeds four row tiles (the hybrid row-tile-owner / column-split proposal)
-        if ((DBG & 4) || ((DBG & 64) && G != 0)) {
+        if ((DBG & 4) || ((DBG & 64) && G != 0) || ((DBG & 128) && (G & 1))) {       // 128: one group in TWO (pairs of waves sharing)
 #pragma unroll
             for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(f[u]));
         } else {
@@ -247,7 +247,7 @@ struct RingT {
         if (bar && !(OPT & 32)) certify_next();
         if (g == 0) next_chunk();
         const lds_byte* a = cbase + (uint32_t)g * (4 * FRAG_BYTES);
-        if ((DBG & 4) || ((DBG & 64) && g != 0)) {
+        if ((DBG & 4) || ((DBG & 64) && g != 0) || ((DBG & 128) && (g & 1))) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(f[u]));
         } else {

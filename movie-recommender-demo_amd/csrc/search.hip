@@ -415,6 +415,12 @@ __device__ __forceinline__ float wave_tau(const float* row, long long n, int r, 
 }
 
 // Round-4 switches of the corpus pass (bits of AMDREC_SCAN_OPT; same-box A/Bs: tools/scan_ab.sh, profiles/r04_scan_*):
+// Both measured and NOT adopted (profiles/r04_scan_ab.log, same box, search-only loop at 512 / 128 queries): 1 -> 0.287-0.297
+// against 0.286-0.287 ms per pass, 2 -> 0.288-0.289 against 0.280-0.282 (0.151 against 0.118 at 128 queries: a 64-row slot
+// leaves the spare waves of a small group half the row parts), 3 -> 0.298-0.301.  Diagnostic bits: 4 = no corpus DMA (the
+// waves compute on whatever the ring holds), 8 = no hit handling.
+//  16  (with 1) the A fragments are carried across the units: a unit's last MFMAs prefetch the next unit's first fragments
+//   2  ring of four 64-row slots instead of two 128-row tiles (DESIGN section 7.3's experiment): DMA three slots ahead
 //   1  j-major MFMA order with the threshold scan of the PREVIOUS (32 rows x 32 queries) accumulator interleaved between the
 //      MFMAs of the current one: the scan (and its hit path) used to run after a quarter's last MFMA with the matrix pipe
 //      idle - and both waves of a SIMD reach that point together, the tile barrier keeps them in step.  Costs a second
@@ -454,17 +460,23 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     constexpr int CPR = 2 * KS;                                  // 16-byte chunks per row
     constexpr int FM = CPR < 16 ? CPR - 1 : 15;                  // swizzle mask
     constexpr int FS = CPR >= 16 ? 0 : (CPR == 8 ? 1 : 2);       // swizzle row shift
-    constexpr int TILE_CHUNKS = SCAN_ROWS * CPR;
+    // SCAN_OPT & 2: the ring is FOUR slots of 64 rows instead of two of 128 (same 128 KB): a slot's DMA is issued three slots
+    // ahead of its first read instead of one tile ahead, and the workgroup meets at a barrier every 64 rows
+    constexpr bool RING4 = (SCAN_OPT & 2) != 0 && KS >= 4;
+    constexpr int TR = RING4 ? 64 : SCAN_ROWS;                   // corpus rows per ring slot
+    constexpr int NSLOT = RING4 ? 4 : 2;
+    constexpr int QPT = TR / 32;                                 // 32-row quarters per slot
+    constexpr int TILE_CHUNKS = TR * CPR;
     constexpr int PASSES = TILE_CHUNKS / 512;
     constexpr int AHEAD = KS < 4 ? KS : 4;                       // A fragments read ahead of their MFMA
     static_assert(TILE_CHUNKS % 512 == 0, "tile must fill whole DMA passes");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* tilebuf = lds;                                                  // [2][TILE_CHUNKS * 16]
+    unsigned char* tilebuf = lds;                                                  // [NSLOT][TILE_CHUNKS * 16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                        // scalar: wave-uniform branches below
-    unsigned char* hitbase = lds + 2 * TILE_CHUNKS * 16 + w * (SCAN_WHITS * 12);   // this wave's list 0; list 1 is
+    unsigned char* hitbase = lds + NSLOT * TILE_CHUNKS * 16 + w * (SCAN_WHITS * 12);   // this wave's list 0; list 1 is
     constexpr int LIST_STRIDE = 8 * SCAN_WHITS * 12;                               // LIST_STRIDE bytes further
-    int* lcnt = reinterpret_cast<int*>(lds + 2 * TILE_CHUNKS * 16 + SCAN_HIT_BYTES);   // [SCAN_QGROUP] hits per query, this WG
+    int* lcnt = reinterpret_cast<int*>(lds + NSLOT * TILE_CHUNKS * 16 + SCAN_HIT_BYTES);   // [SCAN_QGROUP] hits per query, this WG
     lcnt[tid] = 0;                                                                 // (before the first DMA is in flight)
     const int frow = lane & 31, fh = lane >> 5;
     const int bx = blockIdx.x % nx, by = blockIdx.x / nx;
@@ -474,11 +486,11 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     // queries of their own take a share of the tile's ROWS instead: 1 / 2 / 4 / 8 query waves x up to four 32-row parts.
     const int nqg = nq - by * SCAN_QGROUP < SCAN_QGROUP ? nq - by * SCAN_QGROUP : SCAN_QGROUP;
     const int qsh = nqg <= 64 ? 0 : (nqg <= 128 ? 1 : (nqg <= 256 ? 2 : 3));       // log2 of the query waves
-    const int parts = qsh <= 1 ? 4 : (qsh == 2 ? 2 : 1);
+    const int parts = (8 >> qsh) < QPT ? (8 >> qsh) : QPT;                          // 128-row slots: 4 / 4 / 2 / 1
     const int part = w >> qsh;
     const int q0 = by * SCAN_QGROUP + (w & ((1 << qsh) - 1)) * 64;
     const bool active = q0 < nq && part < parts;
-    const int rq_begin = part * (4 / parts), rq_end = rq_begin + 4 / parts;
+    const int rq_begin = part * (QPT / parts), rq_end = rq_begin + QPT / parts;
     const bool second = q0 + 32 < nq;                                              // second query tile has real queries
     const int ntiles = (int)((nrows + SCAN_ROWS - 1) / SCAN_ROWS);
     const int nrows_i = (int)nrows;                                                // < 2^31 (checked by the entry point)
@@ -501,10 +513,11 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     constexpr int RPP = 512 / CPR;                                 // rows per DMA pass
     const int drow = tid / CPR;
     const uint32_t lane_off = (uint32_t)(drow * (int)ld16 * 2 + (((tid % CPR) ^ ((drow >> FS) & FM)) * 16));
-    auto dma = [&](int tile, int buf) {
-        const long long row0 = (long long)tile * SCAN_ROWS;
+    auto dma = [&](int row0i, int buf) {                           // TR rows from corpus row `row0i` into ring slot `buf`
+        if (SCAN_OPT & 4) return;                                  // (diagnostic build)
+        const long long row0 = row0i;
         unsigned char* lbase = tilebuf + (size_t)buf * TILE_CHUNKS * 16 + (size_t)(w * 64) * 16;           // wave-uniform
-        if (row0 + SCAN_ROWS <= nrows) {
+        if (row0 + TR <= nrows) {
             const unsigned char* gb = reinterpret_cast<const unsigned char*>(X16) + row0 * ld16 * 2;
 #pragma unroll
             for (int u = 0; u < PASSES; ++u) {
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
 #pragma unroll
             for (int u = 0; u < PASSES; ++u) {
                 long long r = row0 + u * RPP + drow;
-                r = r < nrows ? r : nrows - 1;
+                r = r < nrows ? r : nrows - 1;                     // (a slot wholly past the end reads the last row: never a hit)
                 const unsigned char* g = reinterpret_cast<const unsigned char*>(X16) + r * ld16 * 2 +
                                          (((tid % CPR) ^ ((drow >> FS) & FM)) * 16);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -574,6 +587,7 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
             for (int g = 0; g < 4; ++g) {
                 const float m4 = fmaxf(fmaxf(acc[j][4 * g], acc[j][4 * g + 1]), fmaxf(acc[j][4 * g + 2], acc[j][4 * g + 3]));
                 if (__builtin_expect(__ballot(m4 >= tq[j]) == 0ull, 1)) continue;
+                if (SCAN_OPT & 8) { asm volatile("" ::"v"(m4)); continue; }     // (diagnostic build: the test, never the hit path)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float sc = acc[j][4 * g + e];
@@ -626,20 +640,26 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
     // accumulator `prv` placed behind MFMAs KS/4 - 1, 2 KS/4 - 1, ... (each test - three max, a compare, a ballot - runs in
     // the shadow of the MFMA in front of it; the wave is back at the next, dependent MFMA before that one has finished).
     auto chain_scan = [&](auto j_tag, auto scan_tag, auto full_tag, const unsigned char* lb, int G, f32x16& cur,
-                          const f32x16& prv, float tprv, int qprv0, int prow_prv, uint32_t list_addr, int& wcount) {
+                          const f32x16& prv, float tprv, int qprv0, int prow_prv, uint32_t list_addr, int& wcount,
+                          bf16x8 (&a)[AHEAD], const unsigned char* lb_next) {
         constexpr int J = decltype(j_tag)::value;
         constexpr bool SCAN = decltype(scan_tag)::value;
+        constexpr bool CARRY = (SCAN_OPT & 16) != 0;               // fragments carried across units (see below)
 #pragma unroll
         for (int r = 0; r < 16; ++r) cur[r] = 0.f;
-        bf16x8 a[AHEAD];
+        if constexpr (!CARRY) {
 #pragma unroll
-        for (int s_ = 0; s_ < AHEAD; ++s_) a[s_] = *reinterpret_cast<const bf16x8*>(lb + ((32 * s_) ^ G));
+            for (int s_ = 0; s_ < AHEAD; ++s_) a[s_] = *reinterpret_cast<const bf16x8*>(lb + ((32 * s_) ^ G));
+        }
         // (a compile-time index walk: with a `#pragma unroll` loop the compiler kept the K loop rolled around the group tests'
         //  branches and indexed the query fragments dynamically - 512 bytes of scratch per lane)
         static_for<KS>([&](auto s_tag) {
             constexpr int s_ = decltype(s_tag)::value;
             const bf16x8 c = a[s_ % AHEAD];
             if constexpr (s_ + AHEAD < KS) a[s_ % AHEAD] = *reinterpret_cast<const bf16x8*>(lb + ((32 * (s_ + AHEAD)) ^ G));
+            // SCAN_OPT & 16: the NEXT unit's first fragments are requested behind this unit's last MFMAs (the swizzle term G
+            // is the same for every 32-row quarter), so a unit no longer opens with an LDS round trip on an empty matrix pipe
+            else if constexpr (CARRY) a[s_ % AHEAD] = *reinterpret_cast<const bf16x8*>(lb_next + ((32 * (s_ + AHEAD - KS)) ^ G));
             cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c, qf[J][s_], cur, 0, 0, 0);
             if constexpr (SCAN) {
                 static_for<(4 * (s_ + 1)) / KS - (4 * s_) / KS>([&](auto g_tag) {
@@ -652,8 +672,14 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
         });
     };
 
-    int t = bx;
-    if (t < ntiles) dma(t, 0);
+    // slot sequence of this workgroup: tiles bx, bx + nx, ... of 128 rows, each SPT = 128 / TR slots
+    constexpr int SPT = SCAN_ROWS / TR;
+    const int my_tiles = bx < ntiles ? (ntiles - bx + nx - 1) / nx : 0;
+    const int nslots = my_tiles * SPT;
+    auto slot_row0 = [&](int i) { return (bx + (i / SPT) * nx) * SCAN_ROWS + (i % SPT) * TR; };   // < 2^31 (entry point)
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i)
+        if (i < nslots) dma(slot_row0(i), i);
     // Thresholds.  Batches of <= 8 queries (gm != nullptr): no threshold launch - while the first tile is in flight wave w
     // computes tau of query w from the sample's group maxima (wave_tau: a deterministic function of gm, so every workgroup
     // arrives at the same value), workgroup 0 publishes it for the finalize.  Columns >= nq get NaN: no score compares >= it.
@@ -667,19 +693,21 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                               // first tile landed, tau_sh written
+    if (NSLOT == 2 || nslots < NSLOT - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * PASSES) : "memory");      // slot 0 (the oldest) has landed
+    __syncthreads();                                               // first slot landed, tau_sh written
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + j * 32 + frow;
         tq[j] = (q < nq) ? (gm != nullptr ? tau_sh[q] : tau[q]) : __builtin_nanf("");
     }
-    int it = 0, wprev = 0;                                         // wprev: hits of the previous tile awaiting their append
-    for (; t < ntiles; t += nx, ++it) {
-        const int buf = it & 1;
-        // previous tile's hits: slots from the LDS counters, keys to the segment - issued BEFORE this tile's DMA so that the
-        // end-of-tile wait for the DMA (vmcnt counts in order) never waits for these stores
-        const unsigned char* lprev = hitbase + (buf ^ 1) * LIST_STRIDE;
+    int it = 0, wprev = 0;                                         // wprev: hits of the previous slot awaiting their append
+    for (; it < nslots; ++it) {
+        const int buf = it % NSLOT, lst = it & 1;
+        const int prow0 = slot_row0(it);
+        // previous slot's hits: slots from the LDS counters, keys to the segment - issued BEFORE this slot's DMA so that the
+        // end-of-slot wait for the DMA (vmcnt counts in order) never waits for these stores
+        const unsigned char* lprev = hitbase + (lst ^ 1) * LIST_STRIDE;
         const int npend = wprev < SCAN_WHITS ? wprev : SCAN_WHITS;
         for (int h = lane; h < npend; h += 64)
             append(reinterpret_cast<const int*>(lprev + SCAN_WHITS * 8)[h],
@@ -687,7 +715,8 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
         // (the DMA goes out right after the barrier: issuing it behind the first quarter's MFMAs, the move that gained 4 % in
         // the row-owner kernel, cost 30 % here - 0.355 against 0.268 ms at 512 queries, profiles/r03_scan_late_dma_ab.log: with a
         // two-deep ring the next tile needs the whole of this tile's compute time to land)
-        if (t + nx < ntiles) dma(t + nx, buf ^ 1);
+        // the slot read NSLOT - 1 iterations from now: its ring slot was read in the previous iteration
+        if (it + NSLOT - 1 < nslots) dma(slot_row0(it + NSLOT - 1), (it + NSLOT - 1) % NSLOT);
         int wcount = 0;
         if (active) {
             // fragment address = lane row base + compile-time row offset + ((32 s) ^ G): the swizzle term depends on
@@ -696,8 +725,8 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
             int G = (fh ^ ((frow >> FS) & FM)) << 4;
             const unsigned char* lb = tilebuf + (size_t)buf * TILE_CHUNKS * 16 + frow * CPR * 16;
             const uint32_t list_addr =
-                (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)(hitbase + buf * LIST_STRIDE);
-            const bool full = (long long)(t + 1) * SCAN_ROWS <= nrows;
+                (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)(hitbase + lst * LIST_STRIDE);
+            const bool full = prow0 + TR <= nrows_i;
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>;
@@ -708,17 +737,24 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
                 const int qa = q0, qb = q0 + 32;
                 auto tile_units = [&](auto full_tag) {
                     asm volatile("" : "+v"(G));
-                    chain_scan(I0{}, std::false_type{}, full_tag, lb + rq_begin * 32 * CPR * 16, G, acc0, acc1, 0.f, 0, 0,
-                               list_addr, wcount);
+                    bf16x8 afr[AHEAD];
+                    const unsigned char* l0 = lb + rq_begin * 32 * CPR * 16;
+                    if constexpr ((SCAN_OPT & 16) != 0) {
+#pragma unroll
+                        for (int s_ = 0; s_ < AHEAD; ++s_) afr[s_] = *reinterpret_cast<const bf16x8*>(l0 + ((32 * s_) ^ G));
+                    }
+                    chain_scan(I0{}, std::false_type{}, full_tag, l0, G, acc0, acc1, 0.f, 0, 0, list_addr, wcount, afr, l0);
 #pragma unroll 1
                     for (int rq = rq_begin; rq < rq_end; ++rq) {
                         asm volatile("" : "+v"(G));
-                        const int prow = t * SCAN_ROWS + rq * 32 + 4 * fh;
+                        const int prow = prow0 + rq * 32 + 4 * fh;
                         const unsigned char* lq = lb + rq * 32 * CPR * 16;
-                        chain_scan(I1{}, std::true_type{}, full_tag, lq, G, acc1, acc0, tq[0], qa, prow, list_addr, wcount);
+                        // (the last unit of the slot prefetches its own quarter again: four harmless reads instead of a branch)
+                        const unsigned char* ln = rq + 1 < rq_end ? lq + 32 * CPR * 16 : lq;
+                        chain_scan(I1{}, std::true_type{}, full_tag, lq, G, acc1, acc0, tq[0], qa, prow, list_addr, wcount, afr, ln);
                         if (rq + 1 < rq_end) {
-                            chain_scan(I0{}, std::true_type{}, full_tag, lq + 32 * CPR * 16, G, acc0, acc1, tq[1], qb, prow,
-                                       list_addr, wcount);
+                            chain_scan(I0{}, std::true_type{}, full_tag, ln, G, acc0, acc1, tq[1], qb, prow, list_addr, wcount,
+                                       afr, ln);
                         } else {
                             static_for<4>([&](auto g_tag) { scan_group(full_tag, acc1, g_tag, tq[1], qb, prow, list_addr, wcount); });
                         }
@@ -730,7 +766,7 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
 #pragma unroll 1
             for (int rq = rq_begin; rq < rq_end; ++rq) {
                 asm volatile("" : "+v"(G));
-                const int prow = t * SCAN_ROWS + rq * 32 + 4 * fh;
+                const int prow = prow0 + rq * 32 + 4 * fh;
                 const unsigned char* lq = lb + rq * 32 * CPR * 16;
                 if (second) {
                     if (full) quarter(I2{}, std::true_type{}, lq, G, prow, list_addr, wcount);
@@ -742,10 +778,14 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
             }
         }
         wprev = wcount;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of tile t+nx landed, my hit stores done
-        __syncthreads();                 // tile t consumed by every wave, tile t+nx visible
+        // my share of the NEXT slot has landed, my hit stores are done.  Two slots: the DMA issued above is the youngest
+        // operation and is waited for.  Four slots: only that DMA (PASSES instructions) may stay in flight - everything older,
+        // the next slot's DMA and the appends included, is complete.
+        if (NSLOT == 2 || !(it + NSLOT - 1 < nslots)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PASSES) : "memory");
+        __syncthreads();                 // this slot consumed by every wave, the next one visible
     }
-    // the last tile's hits
+    // the last slot's hits
     const unsigned char* llast = hitbase + ((it & 1) ^ 1) * LIST_STRIDE;
     const int nlast = wprev < SCAN_WHITS ? wprev : SCAN_WHITS;
     for (int h = lane; h < nlast; h += 64)

@@ -222,3 +222,20 @@ def test_a_replaced_parameter_object_changes_the_packing_cache_key():
     k4 = _lib.tensor_versions(m)
     m[0].load_state_dict({"weight": sd["0.weight"], "bias": sd["0.bias"]}, assign=True)   # assign=True on a child
     assert _lib.tensor_versions(m) != k4
+
+
+def test_row_owner_engine_eligibility_names_its_reason():
+    """the fallback from the f16x3 engine to the generic tile GEMMs must be visible.  The reference's default
+    architecture is eligible; the tutorial's (d_model 128, tutorial.ipynb cell 19), an odd d_ff and unfused attention are not,
+    each with its reason."""
+    from amdrec import weights
+    from tests import cases
+    user, ad, nnum, sd, _ = cases.ranker_case("demo", "scaled")
+    assert weights.x3_ineligible_reason(sd, True) is None and weights.x3_eligible(sd, True)
+    assert "fuse_attention" in weights.x3_ineligible_reason(sd, False)
+    _, _, _, sd_t, _ = cases.ranker_case("tutorial", "scaled")
+    assert weights.x3_ineligible_reason(sd_t, True) == "d_model 128 != 256" and not weights.x3_eligible(sd_t, True)
+    sd_ff = synth.ranker_state(user, ad, nnum, seed=3, d_ff=1000)
+    assert weights.x3_ineligible_reason(sd_ff, True) == "d_ff 1000 is not a multiple of 32"
+    sd_big = synth.ranker_state(user, ad, nnum, seed=3, num_layers=6, d_ff=2048)       # parameter blob beyond the LDS area
+    assert "LDS parameter area" in weights.x3_ineligible_reason(sd_big, True)

@@ -20,7 +20,11 @@ def _clustered(n, d, n_clusters, seed, spread=0.35):
 
 
 @pytest.mark.parametrize("n,nlist,nprobe,k,nq", [(20_000, 100, 10, 100, 33), (50_000, 256, 16, 500, 64),
-                                                 (5_000, 64, 64, 50, 5), (30_000, 37, 5, 200, 300)])
+                                                 (5_000, 64, 64, 50, 5), (30_000, 37, 5, 200, 300),
+                                                 # round 4: lists of ~1250 rows and of ~5000 rows - a workgroup of the grouped
+                                                 # scan walks several row tiles of its list, 128-row tiles (longest list
+                                                 # <= 1536 rows) and 256-row tiles
+                                                 (40_000, 32, 8, 300, 64), (80_000, 16, 4, 500, 128)])
 def test_ivf_scan_is_exact_given_centroids(n, nlist, nprobe, k, nq):
     from amdrec.index import FAISSIndex
     xb = _clustered(n, 256, 40, 1)

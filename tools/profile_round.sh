@@ -3,13 +3,16 @@
 #   $OUT/stats  : --kernel-trace --stats of `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-search-sweep ...`
 #   $OUT/pmc*   : five --pmc passes (one counter group each, kernel trace only) of a 3-step run
 # then tools/pmc_summary.py -> $OUT/pmc.json.  Copy what is to be judged into profiles/ (tools/profile_round.sh prints the list).
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/prof_$R
 cd /root/repo
 export TMPDIR=/tmp
 rm -rf $OUT; mkdir -p $OUT
 ARGS="--no-cpu-baseline --no-search-sweep --no-strict-fp32 --no-latency-sweep"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || echo "stats pass failed"
+# the same command with the ranker on the STRICT fp32-MFMA engine: per-kernel stats of linear_256x128 /
+# residual_ln_256x128 / cross_256x128 -> copy to profiles/rNN_bench_kernel_stats_fp32.csv
+rocprofv3 --kernel-trace --stats -d $OUT/stats_fp32 -o stats_fp32 --output-format csv -- python3 bench.py --steps 10 --warmup 3 --ranker-engine fp32 $ARGS > $OUT/bench_under_rocprof_fp32.json 2> $OUT/stats_fp32.err || echo "fp32 stats pass failed"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS"; do
   i=$((i+1))

@@ -111,6 +111,14 @@ if A.index == "ivf":
     for qt in (32, 64):
         tiles = int((((cnt + qt - 1) // qt) * lens).sum().item()) * bench.DIM * 4
         print(f"  list bytes if read once per {qt}-query tile: {tiles / 1e9:.3f} GB (once per probed list: {once / 1e9:.3f} GB)")
+    nf = max(2, A.nprobe // 8)                             # the two-phase scan: nearest nf probes unfiltered (32-query tiles here)
+    for name, pr, qt in (("phase 1", probes[:, :nf], 32), ("phase 2", probes[:, nf:], 64)):
+        c = torch.bincount(pr.reshape(-1), minlength=st.nlist)
+        qtiles = (c + qt - 1) // qt
+        for bq in (128, 256):
+            wgs = int((qtiles * ((lens + bq - 1) // bq)).sum().item())
+            print(f"  {name}: {int(qtiles.sum())} (list, {qt}-query tile) groups, {wgs} row tiles of {bq}; "
+                  f"fp32-MFMA time of those tiles {wgs * 8 * (bq // 32) * (qt // 32) * 16 * 64 / 4 / 256 / 2.4e9 * 1e3:.3f} ms")
     sc = sum(v["total_ms"] for k_, v in rep.items() if k_.startswith("ivf_scan")) / reps
     print(f"  lists: len min/mean/max {int(lens.min())}/{lf.mean():.1f}/{max_len}; queries per probed list mean {cnt.float().mean():.1f} max {int(cnt.max())}; "
           f"scan {sc:.4f} ms = {once / sc / 1e6 / 8000:.3f} of HBM peak on the once-per-list bytes")
