@@ -415,10 +415,15 @@ __device__ __forceinline__ float wave_tau(const float* row, long long n, int r, 
 }
 
 // Round-4 switches of the corpus pass (bits of AMDREC_SCAN_OPT; same-box A/Bs: tools/scan_ab.sh, profiles/r04_scan_*):
-// Both measured and NOT adopted (profiles/r04_scan_ab.log, same box, search-only loop at 512 / 128 queries): 1 -> 0.287-0.297
-// against 0.286-0.287 ms per pass, 2 -> 0.288-0.289 against 0.280-0.282 (0.151 against 0.118 at 128 queries: a 64-row slot
-// leaves the spare waves of a small group half the row parts), 3 -> 0.298-0.301.  Diagnostic bits: 4 = no corpus DMA (the
-// waves compute on whatever the ring holds), 8 = no hit handling.
+// DEFAULT 32.  Measured and NOT adopted (profiles/r04_scan_ab.log, same box, search-only loop at 512 / 128 queries): 1 ->
+// 0.287-0.297 against 0.286-0.287 ms per pass, 17 -> 0.285-0.287 against 0.283-0.287, 2 -> 0.288-0.289 against 0.280-0.282
+// (0.151 against 0.118 at 128 queries: a 64-row slot leaves the spare waves of a small group half the row parts), 3 ->
+// 0.298-0.301.  Adopted: 32 -> 0.289-0.292 against 0.296-0.297 at 512 queries, neutral below.  Diagnostic bits: 4 = no
+// corpus DMA (the waves compute on whatever the ring holds), 8 = no hit handling (old quarter code only).
+//  32  the quarter's LDS-read / MFMA interleave spelled out with sched_group_barrier (the scheduler otherwise hoists all 16
+//      fragment reads of a quarter in front of its first MFMA)
+//  64  (with 32) two accumulator sets ping-pong: the previous quarter's threshold scan rides between the current quarter's
+//      MFMAs and the next quarter's first fragments are requested behind its last ones
 //  16  (with 1) the A fragments are carried across the units: a unit's last MFMAs prefetch the next unit's first fragments
 //   2  ring of four 64-row slots instead of two 128-row tiles (DESIGN section 7.3's experiment): DMA three slots ahead
 //   1  j-major MFMA order with the threshold scan of the PREVIOUS (32 rows x 32 queries) accumulator interleaved between the
@@ -426,7 +431,7 @@ __device__ __forceinline__ float wave_tau(const float* row, long long n, int r, 
 //      idle - and both waves of a SIMD reach that point together, the tile barrier keeps them in step.  Costs a second
 //      read of every A fragment (once per query tile); no extra registers (the two accumulators ping-pong).
 #ifndef AMDREC_SCAN_OPT
-#define AMDREC_SCAN_OPT 0
+#define AMDREC_SCAN_OPT 32
 #endif
 constexpr int SCAN_OPT = AMDREC_SCAN_OPT;
 constexpr int SCAN_ROWS = 128;          // corpus rows per LDS tile
@@ -576,6 +581,19 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
             for (int j = 0; j < NJ; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, qf[j][s_], acc[j], 0, 0, 0);
         }
+        if constexpr ((SCAN_OPT & 32) != 0) {
+            // The source reads a fragment AHEAD k-steps before its MFMAs, but the machine scheduler hoists ALL KS reads of the
+            // quarter to its top (it has the registers) and waits for the last of them before the first MFMA: a quarter then
+            // runs [16 LDS reads, one full wait] [32 MFMAs] [threshold scan] with nothing overlapped - 0.21 ms per pass with
+            // DMA and hits compiled out, against 0.10 at the MFMA rate (profiles/r04_scan_elim.log, the ISA in DESIGN.md).
+            // The schedule is therefore spelled out: AHEAD reads, then per k-step the NJ MFMAs followed by one read.
+            __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);                       // DS reads
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);                      // MFMAs of k-step s_
+                if (s_ + AHEAD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the read AHEAD steps on
+            }
+        }
         // Threshold scan.  A hit is rare per element (~1.4e-3) but a taken branch per element costs more than the
         // MFMAs it follows, so four elements share one test (their maximum; NaN never wins) and the per-element code is
         // out of line.  (A single v_max3 tree + one test over all 16 elements of a tile was measured in a same-box A/B,
@@ -672,6 +690,46 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
         });
     };
 
+    // SCAN_OPT & 64.  One quarter (32 rows x NJ query tiles, k-step major: a fragment feeds both tiles) into `cur`, with (i) the
+    // NEXT quarter's first fragments requested behind its last MFMAs, so that no quarter opens with an LDS round trip on an empty
+    // matrix pipe, and (ii) the threshold scan of the PREVIOUS quarter's accumulators `prv` placed between its MFMAs - one
+    // group of tests behind every KS / 4 k-steps - instead of behind its last MFMA with the pipe idle.  Two accumulator sets
+    // ping-pong (+32 registers, which the spelled-out read schedule of bit 32 had freed).
+    auto step = [&](auto nj_tag, auto scan_tag, auto full_tag, const unsigned char* lq, const unsigned char* lnext, int G,
+                    auto& cur, const auto& prv, int prow_prv, uint32_t list_addr, int& wcount, bf16x8 (&a)[AHEAD]) {
+        constexpr int NJ = decltype(nj_tag)::value;
+        constexpr bool SCAN = decltype(scan_tag)::value;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cur[j][r] = 0.f;
+        static_for<4>([&](auto seg_tag) {                          // four segments of KS / 4 k-steps, a test group behind each
+            constexpr int SEG = decltype(seg_tag)::value;
+            constexpr int S0 = SEG * KS / 4, S1 = (SEG + 1) * KS / 4;
+            static_for<S1 - S0>([&](auto d_tag) {
+                constexpr int s_ = S0 + decltype(d_tag)::value;
+                const bf16x8 c = a[s_ % AHEAD];
+                if constexpr (s_ + AHEAD < KS) a[s_ % AHEAD] = *reinterpret_cast<const bf16x8*>(lq + ((32 * (s_ + AHEAD)) ^ G));
+                else a[s_ % AHEAD] = *reinterpret_cast<const bf16x8*>(lnext + ((32 * (s_ + AHEAD - KS)) ^ G));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c, qf[j][s_], cur[j], 0, 0, 0);
+            });
+#pragma unroll
+            for (int d = 0; d < S1 - S0; ++d) {                    // this segment's schedule: per k-step its MFMAs, then its read
+                __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if constexpr (SCAN) {
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<NJ>([&](auto j_tag) {
+                    constexpr int j = decltype(j_tag)::value;
+                    scan_group(full_tag, prv[j], seg_tag, tq[j], q0 + j * 32, prow_prv, list_addr, wcount);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+
     // slot sequence of this workgroup: tiles bx, bx + nx, ... of 128 rows, each SPT = 128 / TR slots
     constexpr int SPT = SCAN_ROWS / TR;
     const int my_tiles = bx < ntiles ? (ntiles - bx + nx - 1) / nx : 0;
@@ -762,6 +820,67 @@ __global__ __launch_bounds__(512, 1) void scan_filter_kernel(const uint16_t* __r
                 };
                 if (full) tile_units(std::true_type{});
                 else tile_units(std::false_type{});
+            } else if constexpr ((SCAN_OPT & 32) != 0) {
+                // one quarter LOOP per (query tiles, full slot) variant: with the variant chosen inside the loop the compiler
+                // merged the four variants' identical fragment reads in front of the branch - in a different basic block than
+                // their MFMAs, where no schedule can interleave them
+                auto quarters = [&](auto nj_tag, auto full_tag) {
+                    if constexpr ((SCAN_OPT & 64) != 0) {
+                        constexpr int NJ = decltype(nj_tag)::value;
+                        constexpr int QB = 32 * CPR * 16;                      // LDS bytes of a 32-row quarter
+                        f32x16 accA[NJ], accB[NJ];
+                        bf16x8 afr[AHEAD];
+                        asm volatile("" : "+v"(G));
+                        const unsigned char* l0 = lb + rq_begin * QB;
+                        const int pr0 = prow0 + 4 * fh;
+#pragma unroll
+                        for (int s_ = 0; s_ < AHEAD; ++s_) afr[s_] = *reinterpret_cast<const bf16x8*>(l0 + ((32 * s_) ^ G));
+                        // (the slot's last quarter prefetches its own first fragments again: four harmless reads, no branch)
+                        step(nj_tag, std::false_type{}, full_tag, l0, rq_begin + 1 < rq_end ? l0 + QB : l0, G, accA, accB, 0,
+                             list_addr, wcount, afr);
+                        int rq = rq_begin + 1;
+#pragma unroll 1
+                        for (; rq + 1 < rq_end; rq += 2) {                     // quarters rq (into B) and rq + 1 (into A)
+                            asm volatile("" : "+v"(G));
+                            const unsigned char* lq = lb + rq * QB;
+                            step(nj_tag, std::true_type{}, full_tag, lq, lq + QB, G, accB, accA, pr0 + (rq - 1) * 32, list_addr,
+                                 wcount, afr);
+                            step(nj_tag, std::true_type{}, full_tag, lq + QB, rq + 2 < rq_end ? lq + 2 * QB : lq + QB, G, accA, accB,
+                                 pr0 + rq * 32, list_addr, wcount, afr);
+                        }
+                        if (rq < rq_end) {
+                            asm volatile("" : "+v"(G));
+                            const unsigned char* lq = lb + rq * QB;
+                            step(nj_tag, std::true_type{}, full_tag, lq, lq, G, accB, accA, pr0 + (rq - 1) * 32, list_addr, wcount, afr);
+                            static_for<NJ>([&](auto j_tag) {
+                                constexpr int j = decltype(j_tag)::value;
+                                static_for<4>([&](auto g_tag) {
+                                    scan_group(full_tag, accB[j], g_tag, tq[j], q0 + j * 32, pr0 + rq * 32, list_addr, wcount);
+                                });
+                            });
+                        } else {
+                            static_for<NJ>([&](auto j_tag) {
+                                constexpr int j = decltype(j_tag)::value;
+                                static_for<4>([&](auto g_tag) {
+                                    scan_group(full_tag, accA[j], g_tag, tq[j], q0 + j * 32, pr0 + (rq - 1) * 32, list_addr, wcount);
+                                });
+                            });
+                        }
+                        return;
+                    }
+#pragma unroll 1
+                    for (int rq = rq_begin; rq < rq_end; ++rq) {
+                        asm volatile("" : "+v"(G));
+                        quarter(nj_tag, full_tag, lb + rq * 32 * CPR * 16, G, prow0 + rq * 32 + 4 * fh, list_addr, wcount);
+                    }
+                };
+                if (second) {
+                    if (full) quarters(I2{}, std::true_type{});
+                    else      quarters(I2{}, std::false_type{});
+                } else {
+                    if (full) quarters(I1{}, std::true_type{});
+                    else      quarters(I1{}, std::false_type{});
+                }
             } else
 #pragma unroll 1
             for (int rq = rq_begin; rq < rq_end; ++rq) {
@@ -881,55 +1000,69 @@ __global__ __launch_bounds__(512, 1) void sample_max_kernel(const uint16_t* __re
         if (active) {
             int G = (fh ^ ((frow >> FS) & FM)) << 4;
             const unsigned char* lb = lds + (size_t)buf * TILE_CHUNKS * 16 + frow * CPR * 16;
+            // one quarter loop per number of live query tiles, the LDS-read / MFMA interleave spelled out (scan_filter_kernel,
+            // SCAN_OPT 32: with `if (second)` inside the K loop every k-step ended a basic block)
+            auto quarters = [&](auto nj_tag) {
+                constexpr int NJ = decltype(nj_tag)::value;
 #pragma unroll 1
-            for (int rq = rq_begin; rq < rq_end; ++rq) {
-                asm volatile("" : "+v"(G));
-                const unsigned char* lq = lb + rq * 32 * CPR * 16;
-                f32x16 acc[2];
+                for (int rq = rq_begin; rq < rq_end; ++rq) {
+                    asm volatile("" : "+v"(G));
+                    const unsigned char* lq = lb + rq * 32 * CPR * 16;
+                    f32x16 acc[NJ];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-                bf16x8 a[AHEAD];
+                        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                    bf16x8 a[AHEAD];
 #pragma unroll
-                for (int s_ = 0; s_ < AHEAD; ++s_) a[s_] = *reinterpret_cast<const bf16x8*>(lq + ((32 * s_) ^ G));
+                    for (int s_ = 0; s_ < AHEAD; ++s_) a[s_] = *reinterpret_cast<const bf16x8*>(lq + ((32 * s_) ^ G));
 #pragma unroll
-                for (int s_ = 0; s_ < KS; ++s_) {
-                    const bf16x8 cur = a[s_ % AHEAD];
-                    if (s_ + AHEAD < KS) a[s_ % AHEAD] = *reinterpret_cast<const bf16x8*>(lq + ((32 * (s_ + AHEAD)) ^ G));
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, qf[0][s_], acc[0], 0, 0, 0);
-                    if (second) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, qf[1][s_], acc[1], 0, 0, 0);
-                }
-                const long long col0 = (((long long)t * 4 + rq) * 2 + fh) * SUB;
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        const bf16x8 cur = a[s_ % AHEAD];
+                        if (s_ + AHEAD < KS) a[s_ % AHEAD] = *reinterpret_cast<const bf16x8*>(lq + ((32 * (s_ + AHEAD)) ^ G));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int q = q0 + j * 32 + frow;
-                    if (q >= nq) continue;
-                    float* dst = gm + (long long)q * ldm + col0;
-                    if (SUB == 16) {
+                        for (int j = 0; j < NJ; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, qf[j][s_], acc[j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<f32x4*>(dst + 4 * g) = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                    } else {
-                        float m4[4];
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
+                        if (s_ + AHEAD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    const long long col0 = (((long long)t * 4 + rq) * 2 + fh) * SUB;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {       // v > m ? v : m: a NaN score never wins (sample_threshold_kernel's rule)
-                            float m = acc[j][4 * g];
+                    for (int j = 0; j < NJ; ++j) {
+                        const int q = q0 + j * 32 + frow;
+                        if (q >= nq) continue;
+                        float* dst = gm + (long long)q * ldm + col0;
+                        if (SUB == 16) {
 #pragma unroll
-                            for (int e = 1; e < 4; ++e) m = acc[j][4 * g + e] > m ? acc[j][4 * g + e] : m;
-                            m4[g] = m;
-                        }
-                        if (SUB == 4) {
-                            *reinterpret_cast<f32x4*>(dst) = f32x4{m4[0], m4[1], m4[2], m4[3]};
+                            for (int g = 0; g < 4; ++g)
+                                *reinterpret_cast<f32x4*>(dst + 4 * g) = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
                         } else {
-                            float m = m4[0];
+                            float m4[4];
 #pragma unroll
-                            for (int g = 1; g < 4; ++g) m = m4[g] > m ? m4[g] : m;
-                            *dst = m;
+                            for (int g = 0; g < 4; ++g) {       // v > m ? v : m: a NaN score never wins (sample_threshold_kernel's rule)
+                                float m = acc[j][4 * g];
+#pragma unroll
+                                for (int e = 1; e < 4; ++e) m = acc[j][4 * g + e] > m ? acc[j][4 * g + e] : m;
+                                m4[g] = m;
+                            }
+                            if (SUB == 4) {
+                                *reinterpret_cast<f32x4*>(dst) = f32x4{m4[0], m4[1], m4[2], m4[3]};
+                            } else {
+                                float m = m4[0];
+#pragma unroll
+                                for (int g = 1; g < 4; ++g) m = m4[g] > m ? m4[g] : m;
+                                *dst = m;
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (second) quarters(std::integral_constant<int, 2>{});
+            else quarters(std::integral_constant<int, 1>{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
