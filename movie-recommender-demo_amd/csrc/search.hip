@@ -418,7 +418,8 @@ __device__ __forceinline__ float wave_tau(const float* row, long long n, int r, 
 // DEFAULT 32.  Measured and NOT adopted (profiles/r04_scan_ab.log, same box, search-only loop at 512 / 128 queries): 1 ->
 // 0.287-0.297 against 0.286-0.287 ms per pass, 17 -> 0.285-0.287 against 0.283-0.287, 2 -> 0.288-0.289 against 0.280-0.282
 // (0.151 against 0.118 at 128 queries: a 64-row slot leaves the spare waves of a small group half the row parts), 3 ->
-// 0.298-0.301.  Adopted: 32 -> 0.289-0.292 against 0.296-0.297 at 512 queries, neutral below.  Diagnostic bits: 4 = no
+// 0.298-0.301, 96 -> 0.311-0.312 against 0.289-0.290 (13 spilled registers).  Adopted: 32 -> 0.289-0.292 against 0.296-0.297
+// at 512 queries, neutral below.  Diagnostic bits: 4 = no
 // corpus DMA (the waves compute on whatever the ring holds), 8 = no hit handling (old quarter code only).
 //  32  the quarter's LDS-read / MFMA interleave spelled out with sched_group_barrier (the scheduler otherwise hoists all 16
 //      fragment reads of a quarter in front of its first MFMA)
