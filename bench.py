@@ -278,14 +278,23 @@ def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, uc, un, n_users, 
     import oracle
     idx = oracle.search.FlatIndex(DIM)
     idx.add(corpus_cpu)                                   # index build is not timed (nor is it on the GPU)
-    t0 = time.time()
-    ref = oracle.pipeline.recommend(tt_sd, rk_sd, idx, ad_table_cpu, uc[:n_users], un[:n_users], TOP_K, STAGE1_K,
-                                    user_chunk=user_chunk)
-    dt = time.time() - t0
-    threads = _host_threads()
-    numpy_leg = {"value": round(n_users / dt, 2), "unit": "recs/s", "cores": threads, "seconds": round(dt, 1),
-                 "what": "oracle/ (numpy fp32 BLAS + per-query sort): the parity checker"}
+
+    def numpy_leg_run(limit=None):
+        t0 = time.time()
+        if limit:
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=int(limit)):
+                r = oracle.pipeline.recommend(tt_sd, rk_sd, idx, ad_table_cpu, uc[:n_users], un[:n_users], TOP_K, STAGE1_K,
+                                              user_chunk=user_chunk)
+        else:
+            r = oracle.pipeline.recommend(tt_sd, rk_sd, idx, ad_table_cpu, uc[:n_users], un[:n_users], TOP_K, STAGE1_K,
+                                          user_chunk=user_chunk)
+        dt_ = time.time() - t0
+        return r, {"value": round(n_users / dt_, 2), "unit": "recs/s", "cores": int(limit) if limit else _host_threads(),
+                   "seconds": round(dt_, 1), "what": "oracle/ (numpy fp32 BLAS + per-query sort): the parity checker"}
+
     if not torch_leg:
+        ref, numpy_leg = numpy_leg_run()
         return dict(numpy_leg, kind="port", sample=f"the first {n_users} users x {len(corpus_cpu)} ads through oracle/"), ref
     try:
         import faiss  # noqa: F401
@@ -302,6 +311,10 @@ def cpu_baseline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, uc, un, n_users, 
         fi.search(emb, STAGE1_K)
         faiss_leg = {"search_seconds": round(time.time() - t0, 3), "threads": faiss.omp_get_max_threads()}
     tdt, tids = torch_cpu_pipeline(tt_sd, rk_sd, dims, corpus_cpu, ad_table_cpu, uc, un, n_users, user_chunk)
+    try:                                                  # the numpy oracle on the thread count the calibration picked for ATen
+        ref, numpy_leg = numpy_leg_run(torch.get_num_threads())
+    except Exception:
+        ref, numpy_leg = numpy_leg_run()
     same = float(np.mean([set(tids[b].tolist()) == set(ref[b]["ad_ids"]) for b in range(n_users)]))
     tthreads = torch.get_num_threads()
     return {"value": round(n_users / tdt, 2), "unit": "recs/s", "cores": int(tthreads), "kind": "port",
