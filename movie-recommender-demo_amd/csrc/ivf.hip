@@ -226,6 +226,7 @@ using ShapeIvf32 = Shape<1, 4, 1, 2>;   // 32 queries x 256 list rows: for spars
 // of which the second is 19 % full (68 % of the MFMAs multiply padding); 128-row tiles pad the same list to 384 rows.
 using ShapeIvfS = Shape<2, 2, 1, 2>;    // 64 queries x 128 list rows
 using ShapeIvf32S = Shape<1, 4, 1, 1>;  // 32 queries x 128 list rows
+// (double-buffered staging - one barrier per K-step - measured at the per-rank shape: 0.817 against 0.799 ms, not kept)
 
 template <class ShapeIvf>
 __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
 // the k best (by 64-bit key, descending) of row[0 .. n): sorted in buf[0 .. have), have = min(n, k) valid entries first
 // (keys of value 0 = empty slots rank last and are reported invalid by write_result).  All 512 threads call.
 __device__ __forceinline__ int select_sorted_keys(const unsigned long long* row, long long n, int k, int* hist, int* scratch,
-                                                  unsigned long long* buf, int* count) {
+                                                  unsigned long long* buf, unsigned long long* sorted, int* count,
+                                                  int sort_mode) {
     const int tid = threadIdx.x;
     // A key of value 0 is an EMPTY slot, never a row (make_key of a NaN-free score is non-zero): the split select's partial
     // lists are zero-padded, so a pool may hold S * k > k entries of which fewer than k are rows.  Empty slots are skipped
@@ -356,22 +358,36 @@ __device__ __forceinline__ int select_sorted_keys(const unsigned long long* row,
         __syncthreads();
     }
     const int have_all = *count < 2048 ? *count : 2048;
-    int P = 2;
-    while (P < have_all) P <<= 1;             // >= k whenever n >= k (k <= 2048)
-    bitonic_desc(buf, P);
+    __syncthreads();
+    // gathered keys -> `sorted`, descending.  sort_mode 0: the all-LDS bitonic network on a power of two >= the gathered count
+    // (cheap for a few hundred keys, 66 stages - most behind a block barrier - for 2048); 1: the per-wave register sort +
+    // cross-run ranking of the flat search's finalize (topk_utils.hpp sort_desc_runs; keys are unique, zeros rank last: a fixed
+    // ~4 us whatever the count); 2 (default): the network up to 512 keys, the runs beyond.
+    if (sort_mode == 0 || (sort_mode == 2 && have_all <= 512)) {
+        int P = 2;
+        while (P < have_all) P <<= 1;             // >= k whenever n >= k (k <= 2048)
+        bitonic_desc(buf, P);
+        for (int i = threadIdx.x; i < have_all; i += 512) sorted[i] = buf[i];
+        __syncthreads();
+    } else if (have_all <= 1024) {
+        sort_desc_runs<2>(buf, sorted, have_all);
+    } else {
+        sort_desc_runs<4>(buf, sorted, have_all);
+    }
     return have_all < k ? have_all : k;
 }
 
 __global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long long* keys, long long pool_ld,
                                                          const long long* n_pool, int k, float* outD,
-                                                         long long* outI) {
+                                                         long long* outI, int sort_mode) {
     __shared__ int hist[2048];
     __shared__ int scratch[514];
     __shared__ __attribute__((aligned(16))) unsigned long long buf[2048];
+    __shared__ __attribute__((aligned(16))) unsigned long long sorted[2048];
     __shared__ int count;
     const long long q = blockIdx.x;
-    const int have = select_sorted_keys(keys + q * pool_ld, n_pool[q], k, hist, scratch, buf, &count);
-    write_result(buf, have, k, q, outD, outI, 0);
+    const int have = select_sorted_keys(keys + q * pool_ld, n_pool[q], k, hist, scratch, buf, sorted, &count, sort_mode);
+    write_result(sorted, have, k, q, outD, outI, 0);
 }
 
 // Few queries with LARGE pools (one request against nlist 100 / nprobe 10 at 1M ads: 100 000 keys, one workgroup walking
@@ -381,19 +397,20 @@ __global__ __launch_bounds__(512) void ivf_select_kernel(const unsigned long lon
 // the slices, and the order is the key order either way: the same result as ivf_select_kernel.  The ticket returns to 0.
 __global__ __launch_bounds__(512) void ivf_select_split_kernel(const unsigned long long* keys, long long pool_ld,
                                                                const long long* n_pool, int k, unsigned long long* part,
-                                                               int* tickets, float* outD, long long* outI) {
+                                                               int* tickets, float* outD, long long* outI, int sort_mode) {
     __shared__ int hist[2048];
     __shared__ int scratch[514];
     __shared__ __attribute__((aligned(16))) unsigned long long buf[2048];
+    __shared__ __attribute__((aligned(16))) unsigned long long sorted[2048];
     __shared__ int count, last_sh;
     const long long q = blockIdx.y;
     const int s = blockIdx.x, S = gridDim.x, tid = threadIdx.x;
     const long long n = n_pool[q];
     const long long per = (n + S - 1) / S;
     const long long lo = s * per < n ? s * per : n, hi = lo + per < n ? lo + per : n;
-    const int have = select_sorted_keys(keys + q * pool_ld + lo, hi - lo, k, hist, scratch, buf, &count);
+    const int have = select_sorted_keys(keys + q * pool_ld + lo, hi - lo, k, hist, scratch, buf, sorted, &count, sort_mode);
     unsigned long long* mine = part + (q * S + s) * k;
-    for (int i = tid; i < k; i += 512) mine[i] = i < have ? buf[i] : 0ull;
+    for (int i = tid; i < k; i += 512) mine[i] = i < have ? sorted[i] : 0ull;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -409,8 +426,9 @@ __global__ __launch_bounds__(512) void ivf_select_split_kernel(const unsigned lo
     }
     __syncthreads();
     if (!last_sh) return;                                      // block-uniform
-    const int have2 = select_sorted_keys(part + q * S * k, (long long)S * k, k, hist, scratch, buf, &count);
-    write_result(buf, have2, k, q, outD, outI, 0);
+    __syncthreads();                                           // (`sorted` was read above by every thread)
+    const int have2 = select_sorted_keys(part + q * S * k, (long long)S * k, k, hist, scratch, buf, sorted, &count, sort_mode);
+    write_result(sorted, have2, k, q, outD, outI, 0);
 }
 
 // ---- index BUILD: max-inner-product assignment and Lloyd iterations (faiss_retrieval.py:83-95, :118: IndexIVFFlat with an
@@ -771,6 +789,12 @@ extern "C" int amdrec_ivf_coarse_keys(const float* centroids, int nlist, int64_t
     return AMDREC_OK;
 }
 
+// sort of the gathered keys in the select kernels: 2 = adaptive (default); AMDREC_IVF_SORT = 0 / 1 force one form (A/B runs)
+static int ivf_sort_mode() {
+    static const int m = [] { const char* v = getenv("AMDREC_IVF_SORT"); return v ? atoi(v) : 2; }();
+    return m;
+}
+
 extern "C" int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, const int64_t* pool_count, int64_t nq,
                                  int k, float* out_scores, int64_t* out_pos, void* stream) {
     REQUIRE(k >= 1 && k <= AMDREC_MAX_K, "k=%d outside [1,%d]", k, AMDREC_MAX_K);
@@ -779,7 +803,7 @@ extern "C" int amdrec_ivf_select(const uint64_t* pool_keys, int64_t pool_ld, con
     ProfScope prof("ivf_select", 0.0, 0.0, reinterpret_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(ivf_select_kernel, dim3((unsigned)nq), dim3(512), 0, reinterpret_cast<hipStream_t>(stream),
                        (const unsigned long long*)pool_keys, (long long)pool_ld, (const long long*)pool_count, k,
-                       out_scores, (long long*)out_pos);
+                       out_scores, (long long*)out_pos, ivf_sort_mode());
     HIP_TRY(hipGetLastError());
     return AMDREC_OK;
 }
@@ -799,7 +823,7 @@ extern "C" int amdrec_ivf_select_split(const uint64_t* pool_keys, int64_t pool_l
     hipLaunchKernelGGL(ivf_select_split_kernel, dim3((unsigned)slices, (unsigned)nq), dim3(512), 0,
                        reinterpret_cast<hipStream_t>(stream), (const unsigned long long*)pool_keys, (long long)pool_ld,
                        (const long long*)pool_count, k, reinterpret_cast<unsigned long long*>(workspace), tickets, out_scores,
-                       (long long*)out_pos);
+                       (long long*)out_pos, ivf_sort_mode());
     HIP_TRY(hipGetLastError());
     return AMDREC_OK;
 }
