@@ -390,6 +390,9 @@ def roofline_block(name, p, run_tags, steps):
                    f"the fp32 MFMA peak is {FP32_PEAK_TFLOPS}") if x6 else "2*M*N*K against the fp32 MFMA peak"),
             "traffic": tr["hbm_bytes_per_launch"] if tr else None,
             "traffic_source": tr["source"] if tr else None,
+            "traffic_note": ("L2 memory-side requests (FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are counted): the "
+                             "algorithmic bytes + the 8.6 MB weight stream once per XCD L2 and round of workgroups (it does "
+                             "not fit a 4 MB L2): 8.6 MB x 8 x 7.8 = 0.54 GB, served on-die") if x3 and tr else None,
             "alg_bytes_per_launch": round(p["bytes"] / p["launches"]),
             "kernel": name, "launches_per_step": p["launches"] / steps,
             "avg_launch_ms": round(avg_ms, 4),
