@@ -761,12 +761,25 @@ def ivf_search_stats(index, flat_ref, tt, uc, un, prof, steps):
                      "grouped fp32-MFMA list scan, exact k-select)",
            "rows_scanned_per_query": round(per_query, 1), "scan_alg_bytes_per_step": scan_rows * DIM * 4,
            "list_len_min_mean_max": [int(lens.min().item()), round(float(lens.float().mean().item()), 1), int(max_len)]}
-    sc = next((v for k, v in prof.items() if k.startswith("ivf_scan")), None)
-    if sc and sc["total_ms"]:
-        ms = sc["total_ms"] / steps
+    scans = {k: v for k, v in prof.items() if k.startswith("ivf_scan") and v["total_ms"]}
+    if scans:
+        # every scan launch of the step (the two-phase scan has two; its second runs on the bf16 shadow of the lists when the
+        # first phase is selective enough - half the bytes per row - and re-scores the nominated rows from the fp32 lists)
+        ms = sum(v["total_ms"] for v in scans.values()) / steps
+        n_first = max(2, nprobe // 8)
+        two_phase = len(scans) > 1
+        alg = scan_rows * DIM * 4
+        if two_phase:
+            def tiled_rows(pr, qt):
+                c = torch.bincount(pr[pr >= 0].reshape(-1), minlength=st.nlist)
+                return int(((c + qt - 1) // qt * lens).sum().item())
+            mixed = any("bf16" in k for k in scans)
+            alg = tiled_rows(probes[:, :n_first], 64) * DIM * 4 + tiled_rows(probes[:, n_first:], 64) * DIM * (2 if mixed else 4)
+            out["scan_alg_bytes_per_step"] = alg
+            out["scan_phases"] = {k: round(v["total_ms"] / steps, 4) for k, v in sorted(scans.items())}
         out["scan_ms"] = round(ms, 3)
-        out["scan_alg_GBps"] = round(scan_rows * DIM * 4 / ms / 1e6, 1)
-        out["scan_hbm_frac"] = round(scan_rows * DIM * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)
+        out["scan_alg_GBps"] = round(alg / ms / 1e6, 1)
+        out["scan_hbm_frac"] = round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)
     if flat_ref is not None:
         a, _ = index.search_device(emb, STAGE1_K)
         b, _ = flat_ref.search_device(emb, STAGE1_K)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMDREC_ABI_VERSION 9
+#define AMDREC_ABI_VERSION 10
 #define AMDREC_MAX_K 2048
 
 int amdrec_abi_version(void);
@@ -94,6 +94,23 @@ int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, const int64
  * With tau[q] = the k-th score over a SUBSET of the probed lists (a lower bound of the final k-th score) the union of
  * that subset's keys and the kept rows of the remaining lists contains the exact top-k: amdrec.ivf scans the nearest
  * eighth of the probes unfiltered, selects, and scans the rest with this filter - the pool shrinks ~5x. */
+/* The same filter mode with a bf16 PREFILTER (ABI v10; same call site, faiss_retrieval.py:150-155): the (list, query tile)
+ * GEMMs run on `lists_bf16` / `queries_bf16` (round-to-nearest copies made by amdrec_bf16_rows; the lists' copy also yields
+ * max_norm[2] = {largest row norm, largest row rounding-error norm}) with the bf16 MFMA and only nominate rows: a row whose
+ * bf16 score is >= tau_lo[q] is re-scored in fp32 from `lists` / `queries` and appended to query q's pool row at
+ * pool_fill[q]++ if that exact score passes tau[q * ld_tau].  With tau_lo[q] = tau[q] - eps_q (amdrec_ivf_filter_bounds: the
+ * flat search's error bound, see amdrec_flat_search_mixed) every row with fp32 score >= tau is nominated, so the pool
+ * receives the same rows as amdrec_ivf_scan_grouped's filter mode, with fp32 keys.  dim % 8 == 0. */
+int amdrec_ivf_filter_bounds(const float* queries, int64_t nq, int64_t ld_queries, int dim,
+                             const uint16_t* queries_bf16, int64_t ld_queries_bf16, const float* max_norm /*device float[2]*/,
+                             const float* tau, int64_t ld_tau, float* tau_lo /*[nq]*/, void* stream);
+int amdrec_ivf_scan_grouped_mixed(const float* lists, int64_t ld, const uint16_t* lists_bf16, int64_t ld_bf16, int dim,
+                                  const int64_t* row_pos, const int64_t* list_off, int nlist, int64_t max_list_rows,
+                                  const float* queries, int64_t ld_queries, const uint16_t* queries_bf16,
+                                  int64_t ld_queries_bf16, const int64_t* group_off, const int64_t* qtile_prefix,
+                                  int64_t qtile_bound, int qtile, const int64_t* pair_query, uint64_t* pool_keys,
+                                  int64_t pool_ld, int64_t pos_offset, const float* tau, int64_t ld_tau,
+                                  const float* tau_lo /*[nq]*/, int64_t* pool_fill /*[nq]*/, void* stream);
 /* Step 1 as a dense key table (replaces the `index.search` of faiss's IndexFlatIP quantizer inside IndexIVFFlat.search,
  * faiss_retrieval.py:50-55, :150-155): keys[q][c] = 64-bit (score of query q against centroid c, ~c) for every centroid -
  * the pool format of amdrec_ivf_select, which then yields the nprobe best centroids per query (score desc, lower centroid

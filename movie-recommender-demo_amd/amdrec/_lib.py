@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AMDREC_LIB_PATH: developer override for A/B runs of two builds of the library in otherwise identical processes
 LIB_PATH = os.environ.get("AMDREC_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libamdrec.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_K = 2048
 
 
@@ -39,6 +39,9 @@ _SIGNATURES = {
     "amdrec_ivf_scan": [_fp, _i64, _i32, _vp, _vp, _fp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _i64, _vp],
     "amdrec_ivf_scan_grouped": [_fp, _i64, _i32, _vp, _vp, _i32, _i64, _fp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32,
                                 _vp, _i64, _i64, _fp, _i64, _vp, _vp],
+    "amdrec_ivf_filter_bounds": [_fp, _i64, _i64, _i32, _vp, _i64, _fp, _fp, _i64, _fp, _vp],
+    "amdrec_ivf_scan_grouped_mixed": [_fp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i64, _fp, _i64, _vp, _i64, _vp, _vp, _i64,
+                                      _i32, _vp, _vp, _i64, _i64, _fp, _i64, _fp, _vp, _vp],
     "amdrec_ivf_select": [_vp, _i64, _vp, _i64, _i32, _fp, _vp, _vp],
     "amdrec_ivf_select_split": [_vp, _i64, _vp, _i64, _i32, _i32, _fp, _vp, _vp, _sz, _vp, _vp],
     "amdrec_ivf_coarse_keys": [_fp, _i32, _i64, _i32, _fp, _i64, _i64, _vp, _i64, _vp],

@@ -20,6 +20,7 @@ unsharded scan and the merged top-k is bit-identical to the unsharded IVF result
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import numpy as np
@@ -39,6 +40,14 @@ SPARSE_PAIRS_PER_LIST = 24
 MAX_QUERY_TILES = 65535        # grid limit of one amdrec_ivf_scan_grouped launch (pairs / tile + nlist query tiles)
 SELECT_SLICE_KEYS = 4096        # amdrec_ivf_select_split: at least this many pool keys per slice,
 SELECT_MAX_SLICES = 64          # at most this many slices per query
+MIXED_SCAN = True              # second phase of the two-phase scan on a bf16 shadow of the lists (prefilter) + fp32 re-score of
+                               # the nominated rows (csrc/ivf.hip EpiIvfPrefilter); the shadow costs half the lists' bytes again.
+                               # AMDREC_IVF_MIXED=0 / 1 in the environment forces it off / on (A/B runs)
+MIXED_MIN_FIRST_ROWS_PER_K = 32  # ... only when the first phase scans at least this many rows per wanted result: the prefilter
+                               # pays when tau is selective (10M ads / 4096 lists, k = 500: 19.5k first-phase rows, second phase
+                               # 0.77 -> 0.59 ms) and loses when it is not - every nominated row costs a random 1 KB fp32 row
+                               # read (a rank of 8 over the same index, k = 128 against 2440 first-phase rows of weakly
+                               # separated 305-row lists: 0.64 -> 1.37 ms, profiles/r04_ivf_mixed_ab.log)
 TWO_PHASE_MIN_PROBES = 16      # from here on the scan is split: nearest probes unfiltered, the rest filtered by their k-th score (at 10 probes it loses: 0.78 vs 0.41 ms at 64 queries, nlist 100)
 
 
@@ -136,10 +145,25 @@ class IVFState:
             off[1:] = torch.cumsum(counts, 0)
             xs = xb[:n][order].contiguous()
             self._lists = (xs, order.contiguous(), off, counts.to(torch.int64), int(counts.max().item()) if n else 0, n)
+            self._shadow = None                                     # bf16 copy of xs + its {M, D}: made on first use
             # rows of the p longest lists, p = 1 .. nlist: the tight host-side bound of a query's candidate pool
             # (its nprobe probed lists cannot hold more than the nprobe longest; once per list rebuild, like max above)
             self._top_rows = np.cumsum(np.sort(counts.cpu().numpy())[::-1].astype(np.int64))
         return self._lists
+
+    def _list_shadow(self):
+        """bf16 (round-to-nearest) copy of the list-contiguous corpus and max_norm = {largest row norm, largest row
+        rounding-error norm} (amdrec_bf16_rows): the operands of the second-phase prefilter."""
+        if getattr(self, "_shadow", None) is None:
+            xs = self._lists[0]
+            n, d = xs.shape
+            xs16 = torch.empty((n, d), dtype=torch.bfloat16, device=self.device)
+            mx = torch.zeros(2, dtype=torch.float32, device=self.device)
+            if n:
+                _lib.check(_lib.load().amdrec_bf16_rows(_lib.ptr(xs), n, xs.stride(0), d, _lib.ptr(xs16), d, _lib.ptr(mx),
+                                                        _lib.stream_ptr(self.device)))
+            self._shadow = (xs16, mx)
+        return self._shadow
 
     def pool_rows_bound(self, nprobe: int) -> int:
         """Upper bound of the rows a query's ``nprobe`` probed lists hold = the ``nprobe`` longest lists' rows.  Round 2
@@ -227,6 +251,16 @@ class IVFState:
             _lib.check(lib.amdrec_ivf_group(_lib.ptr(pv), nprobe, m, ncol, self.nlist, _lib.ptr(lens), _lib.ptr(base[s:]),
                                             _lib.ptr(n_out), _lib.ptr(pair_q), _lib.ptr(pair_p), _lib.ptr(goff),
                                             _lib.ptr(qtp), qt, _lib.ptr(grp), grp.numel(), st()))
+            if tau is not None and mixed:
+                # bf16 prefilter: tau_lo = tau - eps_q, nominate on the bf16 shadow, re-score the nominated rows in fp32
+                _lib.check(lib.amdrec_ivf_filter_bounds(_lib.ptr(q[s:]), m, q.stride(0), self.dim, _lib.ptr(q16[s:]), q16.stride(0),
+                                                        _lib.ptr(mx16), _lib.ptr(tau), tau.stride(0), _lib.ptr(tau_lo[s:]), st()))
+                _lib.check(lib.amdrec_ivf_scan_grouped_mixed(
+                    _lib.ptr(xs), xs.stride(0), _lib.ptr(xs16), xs16.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off),
+                    self.nlist, max_len, _lib.ptr(q[s:]), q.stride(0), _lib.ptr(q16[s:]), q16.stride(0), _lib.ptr(goff),
+                    _lib.ptr(qtp), (m * ncol) // qt + self.nlist, qt, _lib.ptr(pair_q), _lib.ptr(ws), pool_ld, pos_offset,
+                    _lib.ptr(tau), tau.stride(0), _lib.ptr(tau_lo[s:]), _lib.ptr(fill), st()))
+                return
             _lib.check(lib.amdrec_ivf_scan_grouped(
                 _lib.ptr(xs), xs.stride(0), self.dim, _lib.ptr(spos), _lib.ptr(off), self.nlist, max_len,
                 _lib.ptr(q[s:]), q.stride(0), _lib.ptr(goff), _lib.ptr(qtp), (m * ncol) // qt + self.nlist, qt,
@@ -238,6 +272,15 @@ class IVFState:
         # probes keep only rows with score >= tau, appended behind the first phase's keys -> the final select.  Same
         # result as one unfiltered scan of every probe; the pool that is written and selected from shrinks several-fold.
         two_phase = grouped and nprobe >= TWO_PHASE_MIN_PROBES
+        n_first = max(2, nprobe // 8)
+        force = os.environ.get("AMDREC_IVF_MIXED")
+        selective = n_first * (n / max(1, self.nlist)) >= MIXED_MIN_FIRST_ROWS_PER_K * k
+        mixed = two_phase and self.dim % 8 == 0 and (force == "1" or (force != "0" and MIXED_SCAN and selective))
+        if mixed:
+            xs16, mx16 = self._list_shadow()
+            q16 = torch.empty((nq, self.dim), dtype=torch.bfloat16, device=self.device)
+            _lib.check(lib.amdrec_bf16_rows(_lib.ptr(q), nq, q.stride(0), self.dim, _lib.ptr(q16), q16.stride(0), None, st()))
+            tau_lo = torch.empty((nq,), dtype=torch.float32, device=self.device)
         n_first = max(2, nprobe // 8)
         scratch_n = torch.empty((chunk,), dtype=torch.int64, device=self.device) if two_phase else None
         for s in range(0, nq, chunk):

@@ -323,7 +323,8 @@ class GraphedRecommender:
         # makes the graph stale (documented) but can never leave it with dangling pointers
         idx = rec.faiss_index
         self._pinned = (rec.two_tower_model.user_tower._packed, rec.transformer_ranker._packed, idx._xb, idx._ids,
-                        idx._xb16, idx._maxnorm, rec.ad_features, rec.transformer_ranker._ad_cache, getattr(idx, "_ivf", None) and idx._ivf._lists)
+                        idx._xb16, idx._maxnorm, rec.ad_features, rec.transformer_ranker._ad_cache, getattr(idx, "_ivf", None) and idx._ivf._lists,
+                        getattr(idx, "_ivf", None) and getattr(idx._ivf, "_shadow", None))
 
     @torch.no_grad()
     def __call__(self, user_categorical: torch.Tensor, user_numerical: torch.Tensor):

@@ -174,6 +174,165 @@ struct EpiIvfKeys {
     }
 };
 
+// ---- filter mode with a bf16 PREFILTER (round 4) ------------------------------------------------------------------------
+// The second phase of the two-phase scan keeps only rows with score >= tau_q and most of a batch's (query, probe) pairs are
+// second-phase pairs: 0.64 of the 0.80 ms scan at the per-rank shape of an 8-way sharded 10M index, fp32-MFMA-bound (64
+// queries per list).  Their GEMM runs here on a bf16 shadow of the lists and bf16 queries (v_mfma_f32_32x32x16_bf16: 16x the
+// fp32 MFMA rate, half the list bytes) and decides only which rows MAY pass: a row with fp32 score >= tau has a bf16 score
+// >= tau - eps_q (eps_bound: the flat search's measured-rounding-error bound, with M / D of the list shadow), so every row
+// with approx >= tau_lo[q] = tau[q] - eps_q is RE-SCORED in fp32 from the fp32 list row - one wave per row, one explicit
+// fma chain per lane and a fixed reduction order, so a row's score does not depend on which workgroup handled it - and
+// appended if that exact score passes tau.  The pool holds exact fp32 keys as before; nothing downstream changes.
+// Hits are collected per chunk of four accumulator rows in LDS (the staging area, free after the K loop; capacity = the
+// chunk's element count: no overflow path), then the workgroup's waves share them.
+struct EpiIvfPrefilter {
+    static constexpr const char* name = "ivf_scan_bf16";
+    static constexpr double out_bytes_per_elem = 0.0;
+    static constexpr size_t lds_bytes(int) { return 0; }        // reuses the staging tiles (checked against their size below)
+    const long long* spos;      // positions of this list's rows
+    long long list_rows;
+    const long long* pair_q;    // this list's group: query of member j
+    long long g;
+    unsigned long long* keys;
+    long long pool_ld, pos_offset;
+    const float* tau;           // exact filter: fp32 score >= tau[q * ld_tau] (minus the slack below)
+    long long ld_tau;
+    const float* tau_lo;        // prefilter: bf16 score >= tau_lo[q]
+    unsigned long long* fill;
+    const float* xs;            // this list's fp32 rows
+    long long ld;
+    const float* Q;             // fp32 queries
+    long long ldq;
+    int d;
+    template <class A>
+    __device__ void operator()(A& acc, float* smem) const {
+        constexpr int TP = A::TP, TQ = A::TQ;
+        constexpr int NWAVES = A::WP * A::WQ, NT = 64 * NWAVES;
+        constexpr int CHUNK_R = 4;                                        // accumulator rows per hit round
+        constexpr int CAP = NT * TP * TQ * CHUNK_R;                       // every element of a round can be a hit
+        static_assert((size_t)CAP * 8 + 16 <= (size_t)(A::WP * TP + A::WQ * TQ) * 32 * BK * sizeof(float),
+                      "the hit list must fit the staging tiles");
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        int* cnt = reinterpret_cast<int*>(smem);
+        unsigned long long* hits = reinterpret_cast<unsigned long long*>(smem + 4);     // (query << 32) | row in the list
+        long long rowq[TQ];
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) rowq[j] = acc.q(j, lane);
+        const int d4 = d >> 2;
+#pragma unroll 1
+        for (int r0 = 0; r0 < 16; r0 += CHUNK_R) {
+            if (tid == 0) *cnt = 0;
+            __syncthreads();                                              // (also: every wave has left the staging tiles)
+#pragma unroll
+            for (int i = 0; i < TP; ++i) {
+                long long qv[CHUNK_R];
+                float tv[CHUNK_R];
+#pragma unroll
+                for (int rr = 0; rr < CHUNK_R; ++rr) {
+                    const long long jj = acc.p(i, r0 + rr, lane);
+                    qv[rr] = jj < g ? pair_q[jj] : -1;
+                }
+#pragma unroll
+                for (int rr = 0; rr < CHUNK_R; ++rr) tv[rr] = qv[rr] >= 0 ? tau_lo[qv[rr]] : __builtin_nanf("");
+#pragma unroll
+                for (int rr = 0; rr < CHUNK_R; ++rr)
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) {
+                        const float a = acc.v[i][j][r0 + rr];
+                        // NaN approx (NaN rows / queries): re-score, the exact path decides; NaN threshold: member absent
+                        if ((a >= tv[rr] || (!(a == a) && tv[rr] == tv[rr])) && rowq[j] < list_rows)
+                            hits[atomicAdd(cnt, 1)] = ((unsigned long long)qv[rr] << 32) | (unsigned long long)rowq[j];
+                    }
+            }
+            __syncthreads();
+            const int n = *cnt;
+            for (int h = wave; h < n; h += NWAVES) {                      // one wave per hit: fp32 re-score
+                const unsigned long long e = hits[h];
+                const long long q = (long long)(e >> 32), row = (long long)(e & 0xffffffffull);
+                const f32x4* xr = reinterpret_cast<const f32x4*>(xs + row * ld);
+                const f32x4* qr = reinterpret_cast<const f32x4*>(Q + q * ldq);
+                float part = 0.f;
+                for (int c = lane; c < d4; c += 64) {
+                    const f32x4 x = xr[c], y = qr[c];
+                    part = __builtin_fmaf(x[3], y[3], __builtin_fmaf(x[2], y[2], __builtin_fmaf(x[1], y[1], __builtin_fmaf(x[0], y[0], part))));
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                if (lane == 0) {
+                    float sc = part;
+                    if (!(sc == sc)) sc = -INFINITY;
+                    // the threshold is the k-th score of the first phase, computed by the fp32 MFMA; this sum has another
+                    // order (1e-7-level differences): a slack towards KEEPING never costs exactness, the select decides
+                    const float t = tau[q * ld_tau];
+                    if (sc >= t - 1e-6f * fmaxf(1.f, fabsf(t)) || t == -INFINITY)
+                        (keys + q * pool_ld)[atomicAdd(&fill[q], 1ull)] = make_key(sc, (uint32_t)(spos[row] + pos_offset));
+                }
+            }
+            __syncthreads();                                              // the list is reset by the next round
+        }
+    }
+};
+
+// tau_lo[q] = tau[q] - eps_q for the prefilter above: one wave per query (||q||, ||bf16(q) - q|| from the two copies of the
+// query, M / D from the list shadow's max_norm).  tau = -inf (fewer than k rows in the first phase) stays -inf.
+__global__ __launch_bounds__(256) void ivf_filter_bounds_kernel(const float* Q, long long ldq, const uint16_t* Q16, long long ldq16,
+                                                                int d, long long nq, const float* max_norm, const float* tau,
+                                                                long long ld_tau, float* tau_lo) {
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    float qn = 0.f, dqn = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float v = Q[q * ldq + c];
+        const float b = __uint_as_float((uint32_t)Q16[q * ldq16 + c] << 16);
+        qn += v * v;
+        dqn += (b - v) * (b - v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { qn += __shfl_xor(qn, o, 64); dqn += __shfl_xor(dqn, o, 64); }
+    if (lane == 0) {
+        const float eps = eps_bound(sqrtf(qn), sqrtf(dqn) * 1.0001f, max_norm[0], max_norm[1], d);
+        const float t = tau[q * ld_tau];
+        tau_lo[q] = (eps < INFINITY) ? t - eps : -INFINITY;               // NaN / inf norms: everything is re-scored
+    }
+}
+
+template <class S>
+__global__ __launch_bounds__(S::NT, 2) void ivf_group_scan_mixed_kernel(
+    const float* xs, long long ld, const uint16_t* xs16, long long ld16, int d, int ksteps, const long long* spos,
+    const long long* list_off, const float* Q, long long ldq, const uint16_t* Q16, long long ldq16, const long long* goff,
+    const long long* qt_prefix, int nlist, const long long* pair_q, unsigned long long* keys, long long pool_ld,
+    long long pos_offset, const float* tau, long long ld_tau, const float* tau_lo, unsigned long long* fill) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const long long y = blockIdx.y;
+    if (y >= qt_prefix[nlist]) return;
+    int lo = 0, hi = nlist;                                                // the tile's list: 64-ary search (ivf_group_scan_kernel)
+    {
+        const int lane = threadIdx.x & 63;
+        while (hi - lo > 1) {
+            const int step = (hi - lo + 63) >> 6;
+            const int idx = lo + lane * step;
+            const bool le = idx < hi && qt_prefix[idx] <= y;
+            const int c = __builtin_popcountll(__ballot(le));
+            const int nlo = lo + (c - 1) * step;
+            hi = nlo + step < hi ? nlo + step : hi;
+            lo = nlo;
+        }
+    }
+    const int l = lo;
+    const long long r0 = list_off[l], len = list_off[l + 1] - r0;
+    if ((long long)blockIdx.x * S::BQ >= len) return;
+    const long long g0 = goff[l], g = goff[l + 1] - g0;
+    // the bf16 matrices as float matrices of d / 2 columns (gemm_core.hpp, Shape::BF16)
+    GatherRows lp{reinterpret_cast<const float*>(Q16), pair_q + g0, g, (int)(ldq16 / 2), d / 2};
+    DenseRows lq{reinterpret_cast<const float*>(xs16 + r0 * ld16), len, (int)(ld16 / 2), d / 2, 30, 1ll << 30};
+    EpiIvfPrefilter epi{spos + r0, len, pair_q + g0, g, keys, pool_ld, pos_offset, tau, ld_tau, tau_lo, fill,
+                        xs + r0 * ld, ld, Q, ldq, d};
+    const long long p0 = (y - qt_prefix[l]) * S::BP;
+    for (long long row0 = (long long)blockIdx.x * S::BQ; row0 < len; row0 += (long long)gridDim.x * S::BQ)
+        gemm_block<S>(lp, lq, epi, ksteps, p0, row0, smem);
+}
+
 // Coarse quantizer as a dense key table (round 3): scores of every query against every centroid -> keys[nq][ld] (64-bit
 // (score, ~centroid), the pool format of ivf_select).  The probes used to come from the general exact search
 // (amdrec_flat_search over the centroid table): with nlist <= 8192 rows that path files EVERY row as a candidate through
@@ -227,6 +386,10 @@ using ShapeIvf32 = Shape<1, 4, 1, 2>;   // 32 queries x 256 list rows: for spars
 using ShapeIvfS = Shape<2, 2, 1, 2>;    // 64 queries x 128 list rows
 using ShapeIvf32S = Shape<1, 4, 1, 1>;  // 32 queries x 128 list rows
 // (double-buffered staging - one barrier per K-step - measured at the per-rank shape: 0.817 against 0.799 ms, not kept)
+using ShapeIvfB = Shape<2, 2, 1, 4, false, true>;      // the bf16-prefilter forms of the four shapes (K-step = 64 bf16)
+using ShapeIvf32B = Shape<1, 4, 1, 2, false, true>;
+using ShapeIvfSB = Shape<2, 2, 1, 2, false, true>;
+using ShapeIvf32SB = Shape<1, 4, 1, 1, false, true>;
 
 template <class ShapeIvf>
 __global__ __launch_bounds__(ShapeIvf::NT, 2) void ivf_group_scan_kernel(
@@ -761,6 +924,80 @@ extern "C" int amdrec_ivf_scan_grouped(const float* lists, int64_t ld, int dim, 
     if (qtile == 64) e = short_lists ? AMDREC_IVF_GROUP_SCAN(ShapeIvfS, "ivf_scan_grouped_64x128") : AMDREC_IVF_GROUP_SCAN(ShapeIvf, "ivf_scan_grouped_64x256");
     else             e = short_lists ? AMDREC_IVF_GROUP_SCAN(ShapeIvf32S, "ivf_scan_grouped_32x128") : AMDREC_IVF_GROUP_SCAN(ShapeIvf32, "ivf_scan_grouped_32x256");
 #undef AMDREC_IVF_GROUP_SCAN
+    HIP_TRY(e);
+    return AMDREC_OK;
+}
+
+template <class S>
+static hipError_t launch_group_scan_mixed(const char* tag, const float* lists, long long ld, const uint16_t* lists16, long long ld16,
+                                          int dim, const long long* row_pos, const long long* list_off, int nlist,
+                                          long long max_list_rows, const float* queries, long long ldq, const uint16_t* q16,
+                                          long long ldq16, const long long* group_off, const long long* qtile_prefix,
+                                          long long qtile_bound, const long long* pair_query, unsigned long long* pool_keys,
+                                          long long pool_ld, long long pos_offset, const float* tau, long long ld_tau,
+                                          const float* tau_lo, unsigned long long* fill, hipStream_t st) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.pending()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_group_scan_mixed_kernel<S>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done.mark();
+    }
+    long long gxl = (max_list_rows + S::BQ - 1) / S::BQ;                  // as launch_group_scan
+    const long long cap = (gxl + 7) / 8;
+    if (gxl > cap) gxl = cap;
+    ProfScope prof(tag, 0.0, 0.0, st);
+    hipLaunchKernelGGL(ivf_group_scan_mixed_kernel<S>, dim3((unsigned)gxl, (unsigned)qtile_bound), dim3(S::NT), S::LDS_BYTES, st,
+                       lists, ld, lists16, ld16, dim, (dim / 2 + BK - 1) / BK, row_pos, list_off, queries, ldq, q16, ldq16,
+                       group_off, qtile_prefix, nlist, pair_query, pool_keys, pool_ld, pos_offset, tau, ld_tau, tau_lo, fill);
+    return hipGetLastError();
+}
+
+extern "C" int amdrec_ivf_filter_bounds(const float* queries, int64_t nq, int64_t ld_queries, int dim,
+                                        const uint16_t* queries_bf16, int64_t ld_queries_bf16, const float* max_norm,
+                                        const float* tau, int64_t ld_tau, float* tau_lo, void* stream) {
+    REQUIRE(dim >= 8 && dim % 8 == 0 && dim <= 2048, "dim=%d must be a multiple of 8 in [8,2048]", dim);
+    if (nq <= 0) return AMDREC_OK;
+    REQUIRE(queries && queries_bf16 && max_norm && tau && tau_lo, "null pointer");
+    REQUIRE(ld_queries >= dim && ld_queries_bf16 >= dim && ld_tau >= 1, "bad leading dimension");
+    ProfScope prof("ivf_filter_bounds", 0.0, 0.0, reinterpret_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(ivf_filter_bounds_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       queries, (long long)ld_queries, queries_bf16, (long long)ld_queries_bf16, dim, (long long)nq, max_norm, tau,
+                       (long long)ld_tau, tau_lo);
+    HIP_TRY(hipGetLastError());
+    return AMDREC_OK;
+}
+
+extern "C" int amdrec_ivf_scan_grouped_mixed(const float* lists, int64_t ld, const uint16_t* lists_bf16, int64_t ld_bf16, int dim,
+                                             const int64_t* row_pos, const int64_t* list_off, int nlist, int64_t max_list_rows,
+                                             const float* queries, int64_t ld_queries, const uint16_t* queries_bf16,
+                                             int64_t ld_queries_bf16, const int64_t* group_off, const int64_t* qtile_prefix,
+                                             int64_t qtile_bound, int qtile, const int64_t* pair_query, uint64_t* pool_keys,
+                                             int64_t pool_ld, int64_t pos_offset, const float* tau, int64_t ld_tau,
+                                             const float* tau_lo, int64_t* pool_fill, void* stream) {
+    REQUIRE(dim >= 8 && dim % 8 == 0 && dim <= 2048, "dim=%d must be a multiple of 8 in [8,2048]", dim);
+    REQUIRE(nlist >= 1, "bad nlist");
+    REQUIRE(qtile == 32 || qtile == 64, "qtile must be 32 or 64 (the value given to amdrec_ivf_group)");
+    if (qtile_bound <= 0 || max_list_rows <= 0) return AMDREC_OK;
+    REQUIRE(qtile_bound <= 65535, "too many (list, query-tile) groups for one launch: chunk the queries");
+    REQUIRE(lists && lists_bf16 && row_pos && list_off && queries && queries_bf16 && group_off && qtile_prefix && pair_query &&
+                pool_keys && tau && tau_lo && pool_fill, "null pointer");
+    REQUIRE(ld % 4 == 0 && ld >= dim && ld_queries >= dim && ld_queries % 4 == 0 && ld_bf16 >= dim && ld_bf16 % 8 == 0 &&
+                ld_queries_bf16 >= dim && ld_queries_bf16 % 8 == 0 && ld_tau >= 1, "bad leading dimension");
+    REQUIRE(((uintptr_t)lists % 16) == 0 && ((uintptr_t)lists_bf16 % 16) == 0 && ((uintptr_t)queries % 16) == 0 &&
+                ((uintptr_t)queries_bf16 % 16) == 0, "lists / queries must be 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool short_lists = max_list_rows <= 1536;
+    hipError_t e;
+#define AMDREC_IVF_GROUP_SCAN_MIXED(SHAPE, TAG)                                                                                     \
+    launch_group_scan_mixed<SHAPE>(TAG, lists, ld, lists_bf16, ld_bf16, dim, (const long long*)row_pos, (const long long*)list_off, \
+                                   nlist, max_list_rows, queries, ld_queries, queries_bf16, ld_queries_bf16,                         \
+                                   (const long long*)group_off, (const long long*)qtile_prefix, qtile_bound,                         \
+                                   (const long long*)pair_query, (unsigned long long*)pool_keys, pool_ld, pos_offset, tau,           \
+                                   (long long)ld_tau, tau_lo, (unsigned long long*)pool_fill, st)
+    if (qtile == 64) e = short_lists ? AMDREC_IVF_GROUP_SCAN_MIXED(ShapeIvfSB, "ivf_scan_grouped_bf16_64x128") : AMDREC_IVF_GROUP_SCAN_MIXED(ShapeIvfB, "ivf_scan_grouped_bf16_64x256");
+    else             e = short_lists ? AMDREC_IVF_GROUP_SCAN_MIXED(ShapeIvf32SB, "ivf_scan_grouped_bf16_32x128") : AMDREC_IVF_GROUP_SCAN_MIXED(ShapeIvf32B, "ivf_scan_grouped_bf16_32x256");
+#undef AMDREC_IVF_GROUP_SCAN_MIXED
     HIP_TRY(e);
     return AMDREC_OK;
 }

@@ -1215,9 +1215,7 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const float* x, long lon
 // (2u + u^2) ||q|| M with u = 2^-8 (every component half an ulp off: tests/test_search_gpu.py::
 // test_mixed_worst_case_rounding, where round 1's u = 2^-9 constant returned a wrong top-k); on random unit vectors
 // ||dq|| ~ ||dx|| ~ 0.0008, i.e. eps ~ 0.0018 instead of 0.0078: half as many candidates survive the prune and are re-scored.
-__device__ __forceinline__ float eps_bound(float qn, float dqn, float M, float D, int d) {
-    return (dqn * (M + D) + qn * D) * 1.0001f + (float)d * 1.2e-7f * qn * (M + D);
-}
+// (eps_bound itself lives in topk_utils.hpp: the IVF scan's bf16 prefilter uses the same bound)
 
 // step 4 of the mixed-precision search: select a_k -> prune -> fp32 re-score -> exact sort -> certificate, one workgroup per
 // query.  The candidate keys (<= CAPK / NT + overflow share per thread) stay in registers for the selection: a 3-pass radix

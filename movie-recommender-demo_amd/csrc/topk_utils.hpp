@@ -148,6 +148,12 @@ __device__ inline void sort_desc_runs(unsigned long long* src, unsigned long lon
     __syncthreads();
 }
 
+// |bf16 inner product - fp32 inner product| of a query against any corpus row (derivation: search.hip, "Error bound of the
+// bf16 pass"): qn = ||q||, dqn = ||bf16(q) - q||, M / D = largest row norm / largest row rounding-error norm of the corpus.
+__device__ __forceinline__ float eps_bound(float qn, float dqn, float M, float D, int d) {
+    return (dqn * (M + D) + qn * D) * 1.0001f + (float)d * 1.2e-7f * qn * (M + D);
+}
+
 __device__ inline void write_result(const unsigned long long* buf, int have, int k, long long q, float* outD,
                                     long long* outI, long long pos_offset) {
     for (int i = threadIdx.x; i < k; i += blockDim.x) {

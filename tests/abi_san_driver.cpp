@@ -50,6 +50,19 @@ int main() {
     EXPECT(amdrec_ivf_scan(fp, 256, 255, ip, ip, fp, 1, 256, ip, ip, 4, reinterpret_cast<uint64_t*>(fake), 16, 0, nullptr) < 0);
     EXPECT(amdrec_ivf_scan(fp, 256, 256, ip, ip, fp, 70000, 256, ip, ip, 4, reinterpret_cast<uint64_t*>(fake), 16, 0, nullptr) < 0);
     EXPECT(amdrec_ivf_select(reinterpret_cast<uint64_t*>(fake), 16, ip, 1, 0, fp, ip, nullptr) < 0);
+    // bf16-prefilter forms of the grouped scan (ABI v10): dim must be a multiple of 8, nothing to do without queries / tiles
+    EXPECT(amdrec_ivf_filter_bounds(fp, 4, 256, 12, reinterpret_cast<uint16_t*>(fake), 256, fp, fp, 1, fp, nullptr) < 0);
+    EXPECT(amdrec_ivf_filter_bounds(fp, 0, 256, 256, reinterpret_cast<uint16_t*>(fake), 256, fp, fp, 1, fp, nullptr) == 0);
+    EXPECT(amdrec_ivf_filter_bounds(fp, 4, 256, 256, nullptr, 256, fp, fp, 1, fp, nullptr) < 0);
+    EXPECT(amdrec_ivf_scan_grouped_mixed(fp, 256, reinterpret_cast<uint16_t*>(fake), 256, 256, ip, ip, 16, 100, fp, 256,
+                                         reinterpret_cast<uint16_t*>(fake), 256, ip, ip, 0, 64, ip, reinterpret_cast<uint64_t*>(fake),
+                                         16, 0, fp, 1, fp, ip, nullptr) == 0);                                     // no tiles
+    EXPECT(amdrec_ivf_scan_grouped_mixed(fp, 256, reinterpret_cast<uint16_t*>(fake), 256, 256, ip, ip, 16, 100, fp, 256,
+                                         reinterpret_cast<uint16_t*>(fake), 256, ip, ip, 8, 48, ip, reinterpret_cast<uint64_t*>(fake),
+                                         16, 0, fp, 1, fp, ip, nullptr) < 0);                                      // qtile 48
+    EXPECT(amdrec_ivf_scan_grouped_mixed(fp, 256, nullptr, 256, 256, ip, ip, 16, 100, fp, 256,
+                                         reinterpret_cast<uint16_t*>(fake), 256, ip, ip, 8, 64, ip, reinterpret_cast<uint64_t*>(fake),
+                                         16, 0, fp, 1, fp, ip, nullptr) < 0);                                      // null shadow
     EXPECT(amdrec_l2_normalize(fp, 256, fp, 256, 0, 256, nullptr) == 0);
     EXPECT(amdrec_remap_ids(ip, ip, 10, ip, 0, nullptr) == 0);
     EXPECT(amdrec_prep_numerical(fp, fp, fp, fp, 0, 13, nullptr) == 0);

@@ -319,3 +319,40 @@ def test_split_select_equals_the_single_workgroup_select(nq, n, k, slices):
     exp = pos[0][order]
     have = min(k, c0)
     assert torch.equal(ref_p[0, :have].cpu(), exp[:have])
+
+
+@pytest.mark.parametrize("n,nlist,nprobe,k,nq", [(60_000, 128, 32, 100, 96), (40_000, 32, 16, 300, 64), (200_000, 64, 16, 500, 40)])
+def test_bf16_prefiltered_second_phase_equals_the_fp32_scan(n, nlist, nprobe, k, nq, monkeypatch):
+    """Round 4: the second phase of the two-phase grouped scan nominates rows on a bf16 shadow of the lists (bf16 MFMA) and
+    re-scores the nominated rows in fp32 (csrc/ivf.hip EpiIvfPrefilter).  Every row the fp32 filter keeps must be kept:
+    the result equals the fp32-only scan's - same ids wherever the scores are not fp32 near-ties at the k-th place - and the
+    oracle's given the probes; the profile shows which scan ran."""
+    from amdrec import _lib, ivf
+    from amdrec.index import FAISSIndex
+    xb, xq = _clustered(n, 256, 50, 11), _clustered(nq, 256, 50, 12)
+    idx = FAISSIndex(256, index_type="IVF", nlist=nlist, nprobe=nprobe)
+    idx.add(xb)
+    assert ivf.use_grouped_scan(nq, nprobe, nlist) and nprobe >= ivf.TWO_PHASE_MIN_PROBES
+    monkeypatch.setenv("AMDREC_IVF_MIXED", "1")            # (the default picks it by the first phase's rows per wanted result)
+    _lib.profile_enable(True)
+    ids_m, D_m = idx.search(xq, k)
+    tags_m = set(_lib.profile_report())
+    monkeypatch.setenv("AMDREC_IVF_MIXED", "0")
+    _lib.profile_enable(True)
+    ids_f, D_f = idx.search(xq, k)
+    tags_f = set(_lib.profile_report())
+    _lib.profile_enable(False)
+    assert any(t.startswith("ivf_scan_grouped_bf16") for t in tags_m) and "ivf_filter_bounds" in tags_m
+    assert not any(t.startswith("ivf_scan_grouped_bf16") for t in tags_f)
+    # same result up to fp32 near-ties at the boundary (a re-scored row's sum has another order than the MFMA's)
+    oracle.search.check_topk(D_f, ids_f, D_m, ids_m, tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
+    assert (ids_m == ids_f).mean() > 0.995
+    # and exact given the probes
+    cent, assign = idx._ivf.centroids.cpu().numpy(), idx._ivf.assign.cpu().numpy()
+    xbn, xqn = oracle.search.normalize_l2(xb), oracle.search.normalize_l2(xq)
+    cs = torch.empty((nq, nprobe), dtype=torch.float32, device="cuda")
+    pr = torch.empty((nq, nprobe), dtype=torch.int64, device="cuda")
+    from amdrec.index import flat_search
+    flat_search(idx._ivf.centroids, nlist, torch.from_numpy(xqn).cuda(), nprobe, cs, pr)
+    rD, rI = oracle.search.ivf_search(xbn, assign, cent, xqn, k, nprobe, probes=pr.cpu().numpy())
+    oracle.search.check_topk(rD, rI, D_m, ids_m, tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
