@@ -204,72 +204,100 @@ struct EpiIvfPrefilter {
     const float* Q;             // fp32 queries
     long long ldq;
     int d;
+    // fp32 score of (list row, query) by the 16 lanes of a quarter wave (sub = lane & 15); every lane returns the sum
+    __device__ __forceinline__ float rescore16(long long row, long long q, int sub) const {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(xs + row * ld);
+        const f32x4* qr = reinterpret_cast<const f32x4*>(Q + q * ldq);
+        float part = 0.f;
+        for (int c = sub; c < (d >> 2); c += 16) {
+            const f32x4 x = xr[c], y = qr[c];
+            part = __builtin_fmaf(x[3], y[3], __builtin_fmaf(x[2], y[2], __builtin_fmaf(x[1], y[1], __builtin_fmaf(x[0], y[0], part))));
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        return part;
+    }
+    // the threshold is the k-th score of the first phase, computed by the fp32 MFMA; the re-score sums in another order
+    // (1e-7-level differences): a slack towards KEEPING never costs exactness, the select decides
+    __device__ __forceinline__ void keep(float sc, long long row, long long q) const {
+        if (!(sc == sc)) sc = -INFINITY;
+        const float t = tau[q * ld_tau];
+        if (sc >= t - 1e-6f * fmaxf(1.f, fabsf(t)) || t == -INFINITY)
+            (keys + q * pool_ld)[atomicAdd(&fill[q], 1ull)] = make_key(sc, (uint32_t)(spos[row] + pos_offset));
+    }
     template <class A>
     __device__ void operator()(A& acc, float* smem) const {
         constexpr int TP = A::TP, TQ = A::TQ;
-        constexpr int NWAVES = A::WP * A::WQ, NT = 64 * NWAVES;
-        constexpr int CHUNK_R = 4;                                        // accumulator rows per hit round
-        constexpr int CAP = NT * TP * TQ * CHUNK_R;                       // every element of a round can be a hit
-        static_assert((size_t)CAP * 8 + 16 <= (size_t)(A::WP * TP + A::WQ * TQ) * 32 * BK * sizeof(float),
-                      "the hit list must fit the staging tiles");
+        constexpr int NWAVES = A::WP * A::WQ;
+        // the nominations of the whole tile in ONE list over the staging tiles; a nomination that does not fit is re-scored
+        // by its own lane on the spot (a tile with thousands of nominations: tau is not selective there)
+        constexpr int CAP = (int)(((size_t)(A::WP * TP + A::WQ * TQ) * 32 * BK * sizeof(float) - 16) / 8);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         int* cnt = reinterpret_cast<int*>(smem);
         unsigned long long* hits = reinterpret_cast<unsigned long long*>(smem + 4);     // (query << 32) | row in the list
         long long rowq[TQ];
 #pragma unroll
         for (int j = 0; j < TQ; ++j) rowq[j] = acc.q(j, lane);
-        const int d4 = d >> 2;
-#pragma unroll 1
-        for (int r0 = 0; r0 < 16; r0 += CHUNK_R) {
-            if (tid == 0) *cnt = 0;
-            __syncthreads();                                              // (also: every wave has left the staging tiles)
+        // member -> query -> prefilter threshold for all of this lane's accumulator rows at once: two dependent round
+        // trips per tile (fetched round by round they were eight)
+        int qv[TP][16];
+        float tv[TP][16];
 #pragma unroll
-            for (int i = 0; i < TP; ++i) {
-                long long qv[CHUNK_R];
-                float tv[CHUNK_R];
+        for (int i = 0; i < TP; ++i)
 #pragma unroll
-                for (int rr = 0; rr < CHUNK_R; ++rr) {
-                    const long long jj = acc.p(i, r0 + rr, lane);
-                    qv[rr] = jj < g ? pair_q[jj] : -1;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const long long jj = acc.p(i, r, lane);
+                qv[i][r] = jj < g ? (int)pair_q[jj] : -1;
+            }
 #pragma unroll
-                for (int rr = 0; rr < CHUNK_R; ++rr) tv[rr] = qv[rr] >= 0 ? tau_lo[qv[rr]] : __builtin_nanf("");
+        for (int i = 0; i < TP; ++i)
 #pragma unroll
-                for (int rr = 0; rr < CHUNK_R; ++rr)
+            for (int r = 0; r < 16; ++r) tv[i][r] = qv[i][r] >= 0 ? tau_lo[qv[i][r]] : __builtin_nanf("");
+        if (tid == 0) *cnt = 0;
+        __syncthreads();                                                  // (also: every wave has left the staging tiles)
 #pragma unroll
-                    for (int j = 0; j < TQ; ++j) {
-                        const float a = acc.v[i][j][r0 + rr];
-                        // NaN approx (NaN rows / queries): re-score, the exact path decides; NaN threshold: member absent
-                        if ((a >= tv[rr] || (!(a == a) && tv[rr] == tv[rr])) && rowq[j] < list_rows)
-                            hits[atomicAdd(cnt, 1)] = ((unsigned long long)qv[rr] << 32) | (unsigned long long)rowq[j];
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) {
+                    const float a = acc.v[i][j][r];
+                    // NaN approx (NaN rows / queries): re-score, the exact path decides; NaN threshold: member absent
+                    if ((a >= tv[i][r] || (!(a == a) && tv[i][r] == tv[i][r])) && rowq[j] < list_rows) {
+                        const int slot = atomicAdd(cnt, 1);
+                        if (slot < CAP) {
+                            hits[slot] = ((unsigned long long)(uint32_t)qv[i][r] << 32) | (unsigned long long)rowq[j];
+                        } else {
+                            const f32x4* xr = reinterpret_cast<const f32x4*>(xs + rowq[j] * ld);
+                            const f32x4* qr = reinterpret_cast<const f32x4*>(Q + (long long)qv[i][r] * ldq);
+                            float sc = 0.f;
+                            for (int c = 0; c < (d >> 2); ++c) {
+                                const f32x4 x = xr[c], y = qr[c];
+                                sc = __builtin_fmaf(x[3], y[3], __builtin_fmaf(x[2], y[2], __builtin_fmaf(x[1], y[1], __builtin_fmaf(x[0], y[0], sc))));
+                            }
+                            keep(sc, rowq[j], qv[i][r]);
+                        }
                     }
-            }
-            __syncthreads();
-            const int n = *cnt;
-            for (int h = wave; h < n; h += NWAVES) {                      // one wave per hit: fp32 re-score
-                const unsigned long long e = hits[h];
-                const long long q = (long long)(e >> 32), row = (long long)(e & 0xffffffffull);
-                const f32x4* xr = reinterpret_cast<const f32x4*>(xs + row * ld);
-                const f32x4* qr = reinterpret_cast<const f32x4*>(Q + q * ldq);
-                float part = 0.f;
-                for (int c = lane; c < d4; c += 64) {
-                    const f32x4 x = xr[c], y = qr[c];
-                    part = __builtin_fmaf(x[3], y[3], __builtin_fmaf(x[2], y[2], __builtin_fmaf(x[1], y[1], __builtin_fmaf(x[0], y[0], part))));
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                if (lane == 0) {
-                    float sc = part;
-                    if (!(sc == sc)) sc = -INFINITY;
-                    // the threshold is the k-th score of the first phase, computed by the fp32 MFMA; this sum has another
-                    // order (1e-7-level differences): a slack towards KEEPING never costs exactness, the select decides
-                    const float t = tau[q * ld_tau];
-                    if (sc >= t - 1e-6f * fmaxf(1.f, fabsf(t)) || t == -INFINITY)
-                        (keys + q * pool_ld)[atomicAdd(&fill[q], 1ull)] = make_key(sc, (uint32_t)(spos[row] + pos_offset));
-                }
-            }
-            __syncthreads();                                              // the list is reset by the next round
+        __syncthreads();
+        const int n = *cnt < CAP ? *cnt : CAP;
+        // four nominations per wave at a time (a quarter wave each), two rounds in flight
+        const int grp = lane >> 4, sub = lane & 15;
+        int h = wave * 4 + grp;
+        for (; h + NWAVES * 4 < n; h += 2 * NWAVES * 4) {
+            const unsigned long long e0 = hits[h], e1 = hits[h + NWAVES * 4];
+            const long long q0 = (long long)(e0 >> 32), r0 = (long long)(e0 & 0xffffffffull);
+            const long long q1 = (long long)(e1 >> 32), r1 = (long long)(e1 & 0xffffffffull);
+            const float s0 = rescore16(r0, q0, sub), s1 = rescore16(r1, q1, sub);
+            if (sub == 0) { keep(s0, r0, q0); keep(s1, r1, q1); }
         }
+        if (h < n) {
+            const unsigned long long e0 = hits[h];
+            const long long q0 = (long long)(e0 >> 32), r0 = (long long)(e0 & 0xffffffffull);
+            const float s0 = rescore16(r0, q0, sub);
+            if (sub == 0) keep(s0, r0, q0);
+        }
+        __syncthreads();                                                  // the staging tiles are the next row tile's again
     }
 };
 
