@@ -45,9 +45,9 @@ MIXED_SCAN = True              # second phase of the two-phase scan on a bf16 sh
                                # AMDREC_IVF_MIXED=0 / 1 in the environment forces it off / on (A/B runs)
 MIXED_MIN_FIRST_ROWS_PER_K = 32  # ... only when the first phase scans at least this many rows per wanted result: the prefilter
                                # pays when tau is selective (10M ads / 4096 lists, k = 500: 19.5k first-phase rows, second phase
-                               # 0.77 -> 0.59 ms) and loses when it is not - every nominated row costs a random 1 KB fp32 row
-                               # read (a rank of 8 over the same index, k = 128 against 2440 first-phase rows of weakly
-                               # separated 305-row lists: 0.64 -> 1.37 ms, profiles/r04_ivf_mixed_ab.log)
+                               # 0.77 -> 0.43 ms); when it is not, every row that passes costs a random 1 KB fp32 row read (a
+                               # rank of 8 over the same index, k = 128 against 2440 first-phase rows of weakly separated
+                               # 305-row lists: 0.64 -> 0.60 ms, profiles/r04_ivf_mixed_ab.log) - not worth the shadow's bytes
 TWO_PHASE_MIN_PROBES = 16      # from here on the scan is split: nearest probes unfiltered, the rest filtered by their k-th score (at 10 probes it loses: 0.78 vs 0.41 ms at 64 queries, nlist 100)
 
 
