@@ -321,7 +321,10 @@ def test_split_select_equals_the_single_workgroup_select(nq, n, k, slices):
     assert torch.equal(ref_p[0, :have].cpu(), exp[:have])
 
 
-@pytest.mark.parametrize("n,nlist,nprobe,k,nq", [(60_000, 128, 32, 100, 96), (40_000, 32, 16, 300, 64), (200_000, 64, 16, 500, 40)])
+@pytest.mark.parametrize("n,nlist,nprobe,k,nq", [(60_000, 128, 32, 100, 96), (40_000, 32, 16, 300, 64), (200_000, 64, 16, 500, 40),
+                                                 # first phase shorter than k (8 lists of ~39 rows): tau = -inf, EVERY row of the second
+                                                 # phase is nominated - the nomination list of a tile overflows into the per-lane path
+                                                 (20_000, 512, 64, 500, 128)])
 def test_bf16_prefiltered_second_phase_equals_the_fp32_scan(n, nlist, nprobe, k, nq, monkeypatch):
     """Round 4: the second phase of the two-phase grouped scan nominates rows on a bf16 shadow of the lists (bf16 MFMA) and
     re-scores the nominated rows in fp32 (csrc/ivf.hip EpiIvfPrefilter).  Every row the fp32 filter keeps must be kept:
@@ -347,6 +350,8 @@ def test_bf16_prefiltered_second_phase_equals_the_fp32_scan(n, nlist, nprobe, k,
     # same result up to fp32 near-ties at the boundary (a re-scored row's sum has another order than the MFMA's)
     oracle.search.check_topk(D_f, ids_f, D_m, ids_m, tau=cases.TOPK_TAU, score_tol=cases.SCORE_ATOL)
     assert (ids_m == ids_f).mean() > 0.995
+    if n == 20_000:                                         # the case is what its comment says
+        assert (n // nlist) * max(2, nprobe // 8) < k
     # and exact given the probes
     cent, assign = idx._ivf.centroids.cpu().numpy(), idx._ivf.assign.cpu().numpy()
     xbn, xqn = oracle.search.normalize_l2(xb), oracle.search.normalize_l2(xq)
