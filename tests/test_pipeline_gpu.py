@@ -109,6 +109,50 @@ def test_reference_api_schema_and_preprocessing():
     assert (num_d.cpu() - torch.cat([h[1] for h in host])).abs().max().item() <= 5e-6
 
 
+def test_reference_api_call_is_one_sync_and_still_raises_on_bad_indices():
+    """Round 4: recommend_tensors (what recommend_ads / batch_recommend end in) validates indices without a mid-call
+    read-back, times its stages with events and brings ids + scores + verdict back in ONE copy.  Same results as the
+    device-resident call; an out-of-range user index still raises IndexError (torch.nn.Embedding's behaviour in the
+    reference, two_tower_model.py:44) before anything is returned, so does an out-of-range ad-feature table, and the dict
+    API skips the per-request check only while the label encoder cannot produce an index outside the models' tables."""
+    from amdrec.pipeline import Preprocessor
+    rec, _, (user, ad, nnum) = _setup(3000, 1.0 / 16)
+    uc_h, un_h = synth.user_batch(user, nnum, 5, seed=77)
+    uc, un = torch.from_numpy(uc_h).cuda(), torch.from_numpy(un_h).cuda()
+    dev = rec.recommend_device(uc, un, 10, 200)
+    res = rec.recommend_tensors(torch.from_numpy(uc_h), torch.from_numpy(un_h), top_k=10, stage1_k=200)   # host tensors in
+    assert [r["ad_ids"] for r in res] == dev["ad_ids"].cpu().tolist()
+    sc = dev["scores"].cpu().numpy()
+    for b, r in enumerate(res):
+        assert r["scores"]["ctr"] == sc[0, b].tolist() and r["scores"]["revenue"] == sc[2, b].tolist()
+        t = r["timing"]
+        assert 0 < t["stage1_ms"] <= t["total_ms"] and abs(t["stage1_ms"] + t["stage2_ms"] - t["total_ms"]) < 1e-9
+    bad = uc_h.copy()
+    bad[3, 2] = list(user.values())[2]                      # == cardinality: one past the last row
+    with pytest.raises(IndexError):
+        rec.recommend_tensors(torch.from_numpy(bad), torch.from_numpy(un_h))
+    bad[3, 2] = -1
+    with pytest.raises(IndexError):
+        rec.recommend_tensors(torch.from_numpy(bad), torch.from_numpy(un_h))
+    assert rec.recommend_tensors(torch.from_numpy(uc_h), torch.from_numpy(un_h), stage1_k=200)[0]["ad_ids"] == res[0]["ad_ids"]
+    # dict API: an encoder with MORE classes than the tables have rows is not trusted - its out-of-table index raises
+    classes = {c: [f"cat_{j}" for j in range(card + 3)] for c, card in user.items()}
+    rec.preprocessor = Preprocessor(classes, [f"I{i}" for i in range(1, 14)], np.zeros(13), np.ones(13))
+    assert not rec._encoder_fits()
+    u = {"categorical": {f"C{i}": "cat_1" for i in range(1, 7)}, "numerical": {}}
+    assert len(rec.recommend_ads(u)["ad_ids"]) == 10
+    u["categorical"]["C2"] = f"cat_{list(user.values())[1] + 2}"
+    with pytest.raises(IndexError):
+        rec.recommend_ads(u)
+    classes = {c: [f"cat_{j}" for j in range(card)] for c, card in user.items()}
+    rec.preprocessor = Preprocessor(classes, [f"I{i}" for i in range(1, 14)], np.zeros(13), np.ones(13))
+    assert rec._encoder_fits()
+    # the ad-feature table is validated once per table, not per request
+    rec.ad_features[7, 0] = list(ad.values())[0]
+    with pytest.raises(IndexError):
+        rec.recommend_tensors(uc, un)
+
+
 def test_microbatcher_over_the_device_pipeline():
     """Concurrent recommend_ads callers coalesced into batch_recommend passes return what a direct call returns."""
     import threading

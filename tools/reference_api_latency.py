@@ -1,7 +1,7 @@
 """Dev tool: latency of the REFERENCE API call (AdRecommenderInference.recommend_ads, inference.py:199: a dict of strings and
 floats in, a dict of lists out - host label encoding, H2D, the device path, the reference's stage timing syncs, D2H) on
 BASELINE configs[0]'s model_dir (10 000 synthetic samples, default IVF(100,10) index over 7 000 ads), beside the device-resident
-call.  usage: python tools/reference_api_latency.py"""
+call.  usage: python tools/reference_api_latency.py [--prev]"""
 import os
 import sys
 import tempfile
@@ -14,7 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "movie-recommender-demo_amd"))
 from amdrec import prep, synth  # noqa: E402
-from amdrec.pipeline import AD_COLS, USER_COLS, AdRecommenderInference, build_faiss_index  # noqa: E402
+if "--prev" in sys.argv:          # A/B against a copy of the previous pipeline module placed at amdrec/pipeline_prev.py
+    from amdrec.pipeline_prev import AD_COLS, USER_COLS, AdRecommenderInference, build_faiss_index  # noqa: E402
+else:
+    from amdrec.pipeline import AD_COLS, USER_COLS, AdRecommenderInference, build_faiss_index  # noqa: E402
 from amdrec.towers import TwoTowerModel  # noqa: E402
 
 t = lambda sd: {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}   # noqa: E731
