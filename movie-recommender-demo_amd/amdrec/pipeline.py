@@ -392,9 +392,8 @@ class TwoStageRetriever:
                                                transformer_ranker=self.transformer_ranker,
                                                faiss_index=self.faiss_index, ad_features=ad_features_lookup)
             self._rec_table = ad_features_lookup
-        out = self._rec.recommend_device(uc[:1], un[:1], stage2_k, stage1_k, check_indices=True)
-        ctr = out["scores"][out["tasks"].index("ctr"), 0]
-        return out["ad_ids"][0].tolist(), ctr.tolist()                            # :359-369 (ids, ctr probabilities)
+        r = self._rec.recommend_tensors(uc[:1], un[:1], stage2_k, stage1_k)[0]    # one synchronisation, indices validated
+        return r["ad_ids"], r["scores"]["ctr"]                                    # :359-369 (ids, ctr probabilities)
 
 
 class GraphedRecommender:
