@@ -173,11 +173,10 @@ def test_stream_ptr_device_scope_is_restored_by_check(monkeypatch):
         state["log"].append(state["cur"])
     monkeypatch.setattr(torch.cuda, "set_device", set_device)
 
-    class S:
-        cuda_stream = 1234
-    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: S())
+    asked = []
+    monkeypatch.setattr(_lib, "_raw_stream", lambda idx: asked.append(idx) or 1234)   # (the C-side raw-stream getter)
     p = _lib.stream_ptr(torch.device("cuda", 3))
-    assert p.value == 1234 and state["cur"] == 3
+    assert p.value == 1234 and state["cur"] == 3 and asked == [3]
     _lib.check(0)
     assert state["cur"] == 0 and state["log"] == [3, 0]
     _lib.stream_ptr(torch.device("cuda", 0))                 # already current: no switch, nothing to restore
