@@ -766,7 +766,8 @@ def ivf_search_stats(index, flat_ref, tt, uc, un, prof, steps):
         # every scan launch of the step (the two-phase scan has two; its second runs on the bf16 shadow of the lists when the
         # first phase is selective enough - half the bytes per row - and re-scores the nominated rows from the fp32 lists)
         ms = sum(v["total_ms"] for v in scans.values()) / steps
-        n_first = max(2, nprobe // 8)
+        from amdrec.ivf import first_phase_probes
+        n_first = first_phase_probes(nprobe)
         two_phase = len(scans) > 1
         alg = scan_rows * DIM * 4
         if two_phase:

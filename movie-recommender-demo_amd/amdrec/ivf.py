@@ -70,6 +70,12 @@ def _assign(x: torch.Tensor, cent: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def first_phase_probes(nprobe: int) -> int:
+    """Probes of the two-phase scan's unfiltered first phase: the nearest eighth (AMDREC_IVF_FIRST_DIV overrides the 8 for
+    A/B runs)."""
+    return max(2, nprobe // max(1, int(os.environ.get("AMDREC_IVF_FIRST_DIV", "8"))))
+
+
 def use_grouped_scan(nq: int, nprobe: int, nlist: int) -> bool:
     """List-major (grouped) scan or one workgroup set per (query, probe) pair?  The grouped scan reads a probed list once
     per query tile, the pair scan once per probing query - but at the HBM rate whatever the lists' lengths (their rows are
@@ -272,7 +278,7 @@ class IVFState:
         # probes keep only rows with score >= tau, appended behind the first phase's keys -> the final select.  Same
         # result as one unfiltered scan of every probe; the pool that is written and selected from shrinks several-fold.
         two_phase = grouped and nprobe >= TWO_PHASE_MIN_PROBES
-        n_first = max(2, nprobe // 8)
+        n_first = first_phase_probes(nprobe)
         force = os.environ.get("AMDREC_IVF_MIXED")
         selective = n_first * (n / max(1, self.nlist)) >= MIXED_MIN_FIRST_ROWS_PER_K * k
         mixed = two_phase and self.dim % 8 == 0 and (force == "1" or (force != "0" and MIXED_SCAN and selective))
@@ -281,7 +287,6 @@ class IVFState:
             q16 = torch.empty((nq, self.dim), dtype=torch.bfloat16, device=self.device)
             _lib.check(lib.amdrec_bf16_rows(_lib.ptr(q), nq, q.stride(0), self.dim, _lib.ptr(q16), q16.stride(0), None, st()))
             tau_lo = torch.empty((nq,), dtype=torch.float32, device=self.device)
-        n_first = max(2, nprobe // 8)
         scratch_n = torch.empty((chunk,), dtype=torch.int64, device=self.device) if two_phase else None
         for s in range(0, nq, chunk):
             m = min(chunk, nq - s)
