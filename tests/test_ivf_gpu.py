@@ -321,6 +321,30 @@ def test_split_select_equals_the_single_workgroup_select(nq, n, k, slices):
     assert torch.equal(ref_p[0, :have].cpu(), exp[:have])
 
 
+@pytest.mark.parametrize("dim", [64, 96, 136])
+def test_bf16_prefiltered_second_phase_at_other_dimensions_and_with_nan_rows(dim, monkeypatch):
+    """The prefiltered scan at dimensions that are not a whole number of 64-element bf16 K-steps (96, 136: the last step is
+    masked) and with NaN / inf rows in the lists: a NaN bf16 score is nominated and the fp32 re-score decides (a NaN row ranks
+    last, as in the fp32 scan).  Forced on vs forced off: same result."""
+    from amdrec.index import FAISSIndex
+    n, nlist, nprobe, k, nq = 30_000, 64, 32, 200, 80
+    xb, xq = _clustered(n, dim, 40, 21), _clustered(nq, dim, 40, 22)
+    xb[5] = np.nan
+    xb[77, 3] = np.inf
+    idx = FAISSIndex(dim, index_type="IVF", nlist=nlist, nprobe=nprobe)
+    idx.train(xb[100:])                                      # (k-means on the clean rows)
+    idx.add(xb)
+    monkeypatch.setenv("AMDREC_IVF_MIXED", "1")
+    ids_m, D_m = idx.search(xq, k)
+    monkeypatch.setenv("AMDREC_IVF_MIXED", "0")
+    ids_f, D_f = idx.search(xq, k)
+    fin = np.isfinite(D_f)
+    assert np.array_equal(np.isfinite(D_m), fin)
+    oracle.search.check_topk(np.where(fin, D_f, -np.inf), ids_f, np.where(fin, D_m, -np.inf), ids_m, tau=cases.TOPK_TAU,
+                             score_tol=cases.SCORE_ATOL)
+    assert not np.isin(ids_m[fin], [5, 77]).any()
+
+
 @pytest.mark.parametrize("n,nlist,nprobe,k,nq", [(60_000, 128, 32, 100, 96), (40_000, 32, 16, 300, 64), (200_000, 64, 16, 500, 40),
                                                  # first phase shorter than k (8 lists of ~39 rows): tau = -inf, EVERY row of the second
                                                  # phase is nominated - the nomination list of a tile overflows into the per-lane path
