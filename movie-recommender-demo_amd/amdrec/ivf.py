@@ -253,6 +253,9 @@ class IVFState:
             """(query, probe) pairs of probe columns [col0, col0 + ncol) grouped by list, then the grouped scan of those
             lists: unfiltered into the per-probe slots of the pool, or (tau, fill) filtered and appended."""
             qt = QTILE_SPARSE if m * ncol < SPARSE_PAIRS_PER_LIST * self.nlist else QTILE
+            if os.environ.get("AMDREC_IVF_QTILE"):                       # A/B runs: "32", "64", or "first,second" per phase
+                f = os.environ["AMDREC_IVF_QTILE"].split(",")
+                qt = int(f[0] if (tau is None or len(f) == 1) else f[1])
             pv = probes[s:, col0:]
             _lib.check(lib.amdrec_ivf_group(_lib.ptr(pv), nprobe, m, ncol, self.nlist, _lib.ptr(lens), _lib.ptr(base[s:]),
                                             _lib.ptr(n_out), _lib.ptr(pair_q), _lib.ptr(pair_p), _lib.ptr(goff),
