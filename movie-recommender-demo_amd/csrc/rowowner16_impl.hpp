@@ -47,6 +47,7 @@ constexpr int DMA_PER_WAVE = CHUNK_FRAGS / WAVES;     // 2 fragment sets per wav
 //  16  static priority 1 for waves 4-7: +-0
 //  32  the next chunk's first fragment reads BEFORE the chunk's vmcnt wait + barrier: -2 % alone, +1.5 % on top of 64
 // 128  ONE barrier per TWO chunks (needs 64): +1 % - barriers are not what the waves wait for
+// 1024 (round 4) s_setprio 1 around the six MFMAs of every group, 0 after them: +0.8 % (profiles/r04_x3_setprio_ab.log)
 // 512  stagger (MI355X_MICROARCH "two waves that run the SAME program with one barrier per block"): waves 4-7 take the
 //      chunk's barrier in front of group 2 instead of group 0, as a second compile-time instantiation of the chain (RingT<2>):
 //      +2 % SLOWER, like its run-time-branch form (removed); also removed after losing their A/Bs: fragment prefetch
@@ -274,12 +275,14 @@ __device__ __forceinline__ f32x4 mfma(const f16x8& a, const f16x8& b, const f32x
 }
 // one group of 4 fragment sets {Ah(t0), Al(t0), Ah(t1), Al(t1)} against one B k-step (bh, bl): 6 MFMAs, two accumulators interleaved
 __device__ __forceinline__ void group6(const f16x8 (&a)[4], const f16x8& bh, const f16x8& bl, f32x4& c0, f32x4& c1) {
+    if (OPT & 1024) __builtin_amdgcn_s_setprio(1);       // (round 4 A/B: issue priority raised for the six MFMAs of a group)
     c0 = mfma(a[0], bl, c0);
     c1 = mfma(a[2], bl, c1);
     c0 = mfma(a[1], bh, c0);
     c1 = mfma(a[3], bh, c1);
     c0 = mfma(a[0], bh, c0);
     c1 = mfma(a[2], bh, c1);
+    if (OPT & 1024) __builtin_amdgcn_s_setprio(0);
 }
 
 __device__ __forceinline__ float reduce_max4(float v) {
