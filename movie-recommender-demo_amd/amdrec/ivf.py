@@ -76,6 +76,16 @@ def first_phase_probes(nprobe: int) -> int:
     return max(2, nprobe // max(1, int(os.environ.get("AMDREC_IVF_FIRST_DIV", "8"))))
 
 
+def use_mixed_scan(n: int, nlist: int, nprobe: int, k: int) -> bool:
+    """Second phase of the two-phase scan on the bf16 shadow of the lists (prefilter + fp32 re-score of the rows that pass)?
+    Only when the first phase is selective: it scans at least MIXED_MIN_FIRST_ROWS_PER_K rows per wanted result, so its k-th
+    score leaves few rows of the second phase to re-score.  AMDREC_IVF_MIXED=0 / 1 forces the answer (A/B runs)."""
+    force = os.environ.get("AMDREC_IVF_MIXED")
+    if force in ("0", "1"):
+        return force == "1"
+    return MIXED_SCAN and first_phase_probes(nprobe) * (n / max(1, nlist)) >= MIXED_MIN_FIRST_ROWS_PER_K * k
+
+
 def use_grouped_scan(nq: int, nprobe: int, nlist: int) -> bool:
     """List-major (grouped) scan or one workgroup set per (query, probe) pair?  The grouped scan reads a probed list once
     per query tile, the pair scan once per probing query - but at the HBM rate whatever the lists' lengths (their rows are
@@ -282,9 +292,7 @@ class IVFState:
         # result as one unfiltered scan of every probe; the pool that is written and selected from shrinks several-fold.
         two_phase = grouped and nprobe >= TWO_PHASE_MIN_PROBES
         n_first = first_phase_probes(nprobe)
-        force = os.environ.get("AMDREC_IVF_MIXED")
-        selective = n_first * (n / max(1, self.nlist)) >= MIXED_MIN_FIRST_ROWS_PER_K * k
-        mixed = two_phase and self.dim % 8 == 0 and (force == "1" or (force != "0" and MIXED_SCAN and selective))
+        mixed = two_phase and self.dim % 8 == 0 and use_mixed_scan(n, self.nlist, nprobe, k)
         if mixed:
             xs16, mx16 = self._list_shadow()
             q16 = torch.empty((nq, self.dim), dtype=torch.bfloat16, device=self.device)

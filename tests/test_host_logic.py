@@ -184,6 +184,26 @@ def test_stream_ptr_device_scope_is_restored_by_check(monkeypatch):
     assert state["log"] == [3, 0]
 
 
+def test_ivf_prefilter_choice_by_first_phase_rows_per_result(monkeypatch):
+    """amdrec.ivf.use_mixed_scan: the bf16-prefiltered second phase only where the first phase's k-th score is selective
+    (configs[4] on one GPU yes; a rank of 8 over the same index and the 1M shapes no); the
+    environment forces it for A/B runs."""
+    from amdrec import ivf
+    monkeypatch.delenv("AMDREC_IVF_MIXED", raising=False)
+    monkeypatch.delenv("AMDREC_IVF_FIRST_DIV", raising=False)
+    assert ivf.first_phase_probes(64) == 8 and ivf.first_phase_probes(10) == 2
+    assert ivf.use_mixed_scan(10_000_000, 4096, 64, 500)           # 8 x 2441 rows for 500 results
+    assert not ivf.use_mixed_scan(1_250_000, 4096, 64, 128)        # 8 x 305 rows for 128
+    assert not ivf.use_mixed_scan(1_000_000, 4096, 64, 500) and not ivf.use_mixed_scan(1_000_000, 1024, 32, 500)
+    monkeypatch.setenv("AMDREC_IVF_MIXED", "1")
+    assert ivf.use_mixed_scan(1_000_000, 4096, 64, 500)
+    monkeypatch.setenv("AMDREC_IVF_MIXED", "0")
+    assert not ivf.use_mixed_scan(10_000_000, 4096, 64, 500)
+    monkeypatch.delenv("AMDREC_IVF_MIXED")
+    monkeypatch.setenv("AMDREC_IVF_FIRST_DIV", "16")
+    assert ivf.first_phase_probes(64) == 4
+
+
 def test_ivf_scan_choice_by_pairs_per_list():
     """amdrec.ivf.use_grouped_scan: list-major only for batches whose (query, probe) pairs share lists (>= 3 per list on
     average, >= 16 queries); thinly shared or short lists take the pair scan, which runs at the HBM rate of its bytes."""
