@@ -1200,9 +1200,15 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const float* x, long lon
             ds += __shfl_xor(ds, o, 64);
         }
         if (lane == 0) {
-            atomicMax(reinterpret_cast<unsigned int*>(max_norm), __float_as_uint(sqrtf(ss)));
+            // the maxima only grow: look first, update only when this row raises one.  An unconditional atomicMax per row
+            // serialised 2 x 10M device-scope atomics on two addresses: 227 ms for a 10M-row shadow that moves 15 GB
+            // (profiles/r04_ivf10m_kernel_stats.csv), 68 GB/s
+            unsigned int* m = reinterpret_cast<unsigned int*>(max_norm);
+            const unsigned int a = __float_as_uint(sqrtf(ss));
             // rounded UP a little: the sum above is itself an fp32 evaluation
-            atomicMax(reinterpret_cast<unsigned int*>(max_norm) + 1, __float_as_uint(sqrtf(ds) * 1.0001f));
+            const unsigned int b = __float_as_uint(sqrtf(ds) * 1.0001f);
+            if (__hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a) atomicMax(m, a);
+            if (__hip_atomic_load(m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < b) atomicMax(m + 1, b);
         }
     }
 }
